@@ -1,0 +1,213 @@
+"""Generate tests/golden/* from the REFERENCE's own modules (build container only).
+
+TEST INFRASTRUCTURE, NOT PRODUCT.  Run:  python -m oracle.gen_golden
+Imports the reference torch modules from /root/reference through oracle/ref_loader.py (package
+__init__ bypass + non-arithmetic helper stand-ins, see that file), loads the deterministic
+dc_vic_amd.synth weights into them with strict=True, runs each stage on seeded inputs and stores
+inputs/outputs as small fixtures.  The fixtures are data (inputs + expected outputs + the
+reference's state-dict key/shape manifest); no reference source is copied.
+
+CompressAI-dependent pieces (entropy models, rANS, CHARM wrapper, comp_model classes) cannot be
+imported -> no fixture -> "parity unpinned" for them.
+"""
+from __future__ import annotations
+
+import contextlib
+import io
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+import yaml
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, ROOT)
+
+from oracle import ref_loader  # noqa: E402
+from dc_vic_amd.synth import synth_state_dict  # noqa: E402
+
+OUT = os.path.join(ROOT, "tests", "golden")
+SEED = 1234
+
+
+def build_reference_modules():
+    ref_loader.install()
+    cfg = yaml.safe_load(open(os.path.join(ref_loader.REF, "config/_base_/model/hyperprior_charm_dual_cond_vic_model_vq_f8_n256.yaml")))
+    top = yaml.safe_load(open(os.path.join(ref_loader.REF, "config/dc_vic_patchgan.yaml")))
+    sub = cfg["subnet"]
+    sub.pop("_delete_", None)
+    for k in ("encoder", "decoder"):
+        sub[k].update(top["subnet"][k])
+    with contextlib.redirect_stdout(io.StringIO()):
+        m = ref_loader.ref("ldm.modules.diffusionmodules.model")
+        q = ref_loader.ref("taming.modules.vqvae.quantize")
+        e = ref_loader.ref("src.models.subnet.autoencoder.elic_dual_beta_ft_autoencoder")
+        h = ref_loader.ref("src.models.subnet.hyperprior.minnen20_hyperprior")
+        s = ref_loader.ref("src.models.subnet.vq_estimator.swin_vq_estimator")
+        f = ref_loader.ref("src.models.subnet.vq_fusion_module")
+        dd = sub["vq_model"]["ddconfig"]
+        mods = {}
+        mods["vq_model.encoder"] = m.Encoder(**dd)
+        mods["vq_model.decoder"] = m.Decoder(**dd)
+        mods["vq_model.quantize"] = q.VectorQuantizer2(256, 4, beta=0.25, sane_index_shape=True)
+        # ldm/models/autoencoder.py:42-43
+        mods["vq_model.quant_conv"] = torch.nn.Conv2d(4, 4, 1)
+        mods["vq_model.post_quant_conv"] = torch.nn.Conv2d(4, 4, 1)
+
+        def mk(cls, key):
+            o = dict(sub[key]); o.pop("type")
+            return cls(**o)
+        mods["encoder"] = mk(e.ElicDualBetaFtVqScEncoder, "encoder")
+        mods["decoder"] = mk(e.ElicDualBetaFtFeatFusionDecoder, "decoder")
+        mods["hyperencoder"] = mk(h.Minnen20HyperEncoder, "hyperencoder")
+        mods["hyperdecoder"] = mk(h.Minnen20HyperDecoder, "hyperdecoder")
+        mods["vq_estimator"] = mk(s.DualBlockSwinVqEstimator, "vq_estimator")
+        mods["fusion_module"] = f.VqDecFusionModule(**sub["fusion_module"])
+    for mod in mods.values():
+        mod.eval()
+    return mods, top
+
+
+def manifest_of(mods):
+    man = {}
+    for p, mod in mods.items():
+        for k, v in mod.state_dict().items():
+            man[p + "." + k] = [list(v.shape), str(v.dtype).replace("torch.", "")]
+    return man
+
+
+def load_synth(mods, man):
+    sd = synth_state_dict(man, SEED)
+    for p, mod in mods.items():
+        own = mod.state_dict()
+        new = {}
+        for k, v in own.items():
+            full = p + "." + k
+            new[k] = sd[full] if full in sd else v      # integer / mask buffers keep the module's own
+        mod.load_state_dict(new, strict=True)
+    return sd
+
+
+def rnd(shape, seed, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(shape, generator=g) * scale
+
+
+def img(shape, seed):
+    g = torch.Generator().manual_seed(seed)
+    return torch.rand(shape, generator=g) * 2 - 1
+
+
+def summ(t: torch.Tensor):
+    t = t.double()
+    return np.array([t.sum().item(), t.abs().sum().item(), (t * t).sum().item()], dtype=np.float64)
+
+
+@torch.no_grad()
+def main():
+    torch.set_num_threads(8)
+    os.makedirs(OUT, exist_ok=True)
+    mods, top = build_reference_modules()
+    man = manifest_of(mods)
+    with open(os.path.join(OUT, "state_dict_manifest.json"), "w") as f:
+        json.dump(man, f, indent=0, sort_keys=True)
+    load_synth(mods, man)
+    G = {}
+    br, bv = top["model"]["selected_beta_rate"], top["model"]["selected_beta_vq"]
+    G["selected_beta_rate"] = np.array(br, dtype=np.float64)
+    G["selected_beta_vq"] = np.array(bv, dtype=np.float64)
+
+    enc, dec = mods["vq_model.encoder"], mods["vq_model.decoder"]
+    quant = mods["vq_model.quantize"]
+    # --- a4: VQGAN encoder + quant_conv (128x128 -> attention at 16x16) and a 64x96 ragged one
+    x = img((1, 3, 128, 128), 11)
+    z_e = mods["vq_model.quant_conv"](enc(x))
+    G["a4_x"] = x.numpy(); G["a4_z"] = z_e.numpy()
+    x2 = img((2, 3, 64, 96), 12)
+    G["a4b_x"] = x2.numpy(); G["a4b_z"] = mods["vq_model.quant_conv"](enc(x2)).numpy()
+    # --- a5: VQ search on the encoder output and on a wide random cloud
+    z_q, _, (_, _, idx) = quant(z_e)
+    G["a5_idx"] = idx.numpy(); G["a5_zq"] = z_q.numpy()
+    zr = rnd((2, 4, 24, 40), 13, 0.01)
+    zq2, _, (_, _, idx2) = quant(zr)
+    G["a5b_z"] = zr.numpy(); G["a5b_idx"] = idx2.numpy(); G["a5b_zq"] = zq2.numpy()
+    # --- a6: ELIC encoder (feat = cat[z_q, onehot]) at q0 and q3
+    oh = torch.nn.functional.one_hot(idx, 256).permute(0, 3, 1, 2).float()
+    feat = torch.cat([z_q, oh], dim=1)
+    for q in (0, 3):
+        y = mods["encoder"](x, feat, br[q], bv[q])
+        G[f"a6_y_q{q}"] = y.numpy()
+    # cond vectors for all five qualities (encoder + decoder MLPs)
+    for name in ("encoder", "decoder"):
+        m = mods[name]
+        conds = []
+        for q in range(5):
+            c = torch.cat([m.embed_1.embed(br[q]), m.embed_2.embed(bv[q])], dim=1)
+            conds.append(m.mlp(c)[0].numpy())
+        G[f"cond_{name}"] = np.stack(conds)
+    # per-batch beta tensors (fourier_enc.py:24-29 accepts [N] tensors)
+    yb = mods["encoder"](img((2, 3, 64, 64), 14), rnd((2, 260, 8, 8), 15, 0.3), torch.tensor([2.29, 0.62]), torch.tensor([3.0, 1.5]))
+    G["a6b_y"] = yb.numpy()
+    # --- a7 / a9 hyper nets
+    y0 = torch.from_numpy(G["a6_y_q0"])
+    z = mods["hyperencoder"](y0)
+    G["a7_z"] = z.numpy()
+    zh = torch.round(rnd((2, 192, 2, 3), 16, 3.0))
+    G["a9_zhat"] = zh.numpy(); G["a9_out"] = mods["hyperdecoder"](zh).numpy()
+    # --- a14 ELIC decoder features
+    yh = rnd((1, 192, 8, 8), 17, 2.0)
+    f1, fd = mods["decoder"].get_feats(yh, br[1], bv[1])
+    G["a14_yhat"] = yh.numpy(); G["a14_feat1"] = f1.numpy()
+    G["a14_b14_crop"] = fd["block_1_4"][:, :, :8, :8].numpy(); G["a14_b14_sum"] = summ(fd["block_1_4"])
+    G["a14_b12_crop"] = fd["block_1_2"][:, :, 10:18, 20:28].numpy(); G["a14_b12_sum"] = summ(fd["block_1_2"])
+    assert torch.equal(fd["block_1_8"], f1)
+    # --- a15 Swin estimator: aligned (16x16) and reflect-padded (12x20)
+    for tag, shp, sd_ in (("a15", (1, 192, 16, 16), 18), ("a15b", (2, 192, 12, 20), 19)):
+        ft = rnd(shp, sd_, 1.0)
+        pe, lg = mods["vq_estimator"](ft)
+        G[f"{tag}_feat"] = ft.numpy(); G[f"{tag}_argmax"] = lg.argmax(1).numpy()
+        G[f"{tag}_logits_crop"] = lg[:, ::16, :4, :4].numpy(); G[f"{tag}_logits_sum"] = summ(lg)
+        G[f"{tag}_pred_embed"] = pe.numpy()
+    # --- a16 + a17: LUT -> post_quant_conv -> fusion decoder
+    idx3 = torch.randint(0, 256, (1, 8, 12), generator=torch.Generator().manual_seed(20))
+    lat = quant.embedding(idx3).permute(0, 3, 1, 2).contiguous()
+    lat = mods["vq_model.post_quant_conv"](lat)
+    cf = {"block_1_8": rnd((1, 192, 8, 12), 21), "block_1_4": rnd((1, 192, 16, 24), 22), "block_1_2": rnd((1, 192, 32, 48), 23)}
+    out = mods["fusion_module"](lat, cf, dec, w=1.0)
+    G["a17_idx"] = idx3.numpy(); G["a17_lat"] = lat.numpy()
+    for k, v in cf.items():
+        G[f"a17_{k}"] = v.numpy()
+    G["a17_out_crop"] = out[:, :, 16:48, 30:62].numpy(); G["a17_out_sum"] = summ(out)
+    G["a17_out_ds"] = out[:, :, ::4, ::4].numpy()
+    # plain VQGAN decoder (no fusion) for the frozen-decoder path
+    out_plain = dec(lat)
+    G["a17p_out_ds"] = out_plain[:, :, ::4, ::4].numpy(); G["a17p_out_sum"] = summ(out_plain)
+    np.savez_compressed(os.path.join(OUT, "stages.npz"), **G)
+
+    # --- a13 wire format from the reference's own codec_utils
+    cu = ref_loader.ref("src.utils.codec_utils")
+    hh = cu.HeaderHandler()
+    W = {}
+    W["hdr_512_768_37p9_q0"] = hh.encode((512, 768), torch.tensor([37.9, -3.0]), 0).hex()
+    W["hdr_256_256_3p99_q4"] = hh.encode((256, 256), torch.tensor([-3.99]), 4).hex()
+    W["hdr_1_65535_0_q2"] = hh.encode((1, 65535), torch.tensor([0.2]), 2).hex()
+    import tempfile
+    with tempfile.TemporaryDirectory() as td:
+        p = os.path.join(td, "a.bin")
+        cu.save_byte_strings(p, [bytes.fromhex(W["hdr_512_768_37p9_q0"]), b"\x01\x02\x03", b"\xaa" * 5])
+        W["container"] = open(p, "rb").read().hex()
+        W["container_loaded"] = [s.hex() for s in cu.load_byte_strings(p)]
+        cu.save_byte_strings(p, [b"", b"\x07"])
+        W["container_empty_first"] = open(p, "rb").read().hex()
+    W["hdr_decode_512_768"] = {k: (list(v) if isinstance(v, tuple) else v) for k, v in hh.decode(bytes.fromhex(W["hdr_512_768_37p9_q0"])).items()}
+    with open(os.path.join(OUT, "wire_format.json"), "w") as f:
+        json.dump(W, f, indent=1, sort_keys=True)
+    tot = sum(os.path.getsize(os.path.join(OUT, n)) for n in os.listdir(OUT))
+    print("wrote", sorted(os.listdir(OUT)), f"{tot/1e6:.2f} MB")
+
+
+if __name__ == "__main__":
+    main()
