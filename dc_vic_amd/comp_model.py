@@ -1,0 +1,488 @@
+"""The DC-VIC codec model (compress / decompress / run_model) on HIP kernels.
+
+Drop-in mirror of the reference's model classes and builders:
+  src/models/__init__.py:14-32 (build_comp_model), src/models/subnet/__init__.py:18-32 (build_subnet),
+  src/models/vq_vae_builder.py:10-23, src/models/subnet/vq_estimator/__init__.py (build_vq_estimator),
+  src/models/comp_model/base_model.py:16-189 (BaseModel),
+  src/models/comp_model/hyperprior_vic_model.py:30-534 (HyperpriorVicModel),
+  src/models/comp_model/hyperprior_dc_vic_model.py:25-483 (HyperpriorDualCondVicModel),
+  src/models/comp_model/hyperprior_charm_dc_vic_model.py:16-91 (HyperpriorCharmDualCondVicModel).
+Same class names / registry keys / method names / state-dict keys / bitstream; inference only.
+Differences by design (MI355X-first):
+  * everything, including hyper-decoder + CHARM, stays on the GPU on both sides (kernels are
+    deterministic and batch-invariant, so encoder and decoder agree bit for bit); only int32
+    symbols / cdf indexes and the final bytes cross PCIe;
+  * `compress_batch` / `decompress_batch` code N images per call (one rANS stream per image, coded
+    in parallel on host threads); `compress` / `decompress` keep the reference's one-image contract.
+"""
+from __future__ import annotations
+
+import os
+from collections import OrderedDict
+from copy import deepcopy
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import ops
+from .charm import Minnen20CharmContextModel  # noqa: F401  (registers)
+from .codec_utils import HeaderHandler
+from .elic import ElicDualBetaFtFeatFusionDecoder, ElicDualBetaFtVqScEncoder  # noqa: F401
+from .entropy import EntropyBottleneck, GaussianMeanScaleConditional, get_scale_table, host_threads
+from .fusion import build_vq_fusion_module
+from .hyperprior import Minnen20HyperDecoder, Minnen20HyperEncoder  # noqa: F401
+from .registry import (CONTEXTMODEL_REGISTRY, DECODER_REGISTRY, ENCODER_REGISTRY, ENTROPYMODEL_REGISTRY,
+                       HYPERDECODER_REGISTRY, HYPERENCODER_REGISTRY, LRP_REGISTRY, MODEL_REGISTRY, VQ_ESTIMATOR_REGISTRY)
+from .swin import DualBlockSwinVqEstimator  # noqa: F401
+from .vqgan import VQModelInterface
+
+Tensor = torch.Tensor
+
+SPLIT_DECODE_RESOLUTION = 1024   # hyperprior_vic_model.py:25-27
+SPLIT_WINDOW_SIZE = 512
+SPLIT_STRIDE = 256
+
+
+def _get(opt, key, default=None):
+    try:
+        return opt[key]
+    except (KeyError, TypeError):
+        return default
+
+
+def build_subnet(subnet_opt: Dict, subnet_type: str):
+    subnet_opt = deepcopy(dict(subnet_opt))
+    network_type = subnet_opt.pop("type")
+    registry = {
+        "encoder": ENCODER_REGISTRY, "decoder": DECODER_REGISTRY, "hyperencoder": HYPERENCODER_REGISTRY,
+        "hyperdecoder": HYPERDECODER_REGISTRY, "context_model": CONTEXTMODEL_REGISTRY,
+        "entropy_model": ENTROPYMODEL_REGISTRY, "residual_predictor": LRP_REGISTRY,
+    }[subnet_type]
+    return registry.get(network_type)(**subnet_opt)
+
+
+def build_vq_estimator(opt: Dict):
+    opt = deepcopy(dict(opt))
+    return VQ_ESTIMATOR_REGISTRY.get(opt.pop("type"))(**opt)
+
+
+def build_pretrained_vq_model(vq_model_opt: Dict, device) -> VQModelInterface:
+    opt = deepcopy(dict(vq_model_opt))
+    ckpt_path = opt.pop("ckpt_path", None)
+    if hasattr(opt.get("ddconfig"), "to_dict"):
+        opt["ddconfig"] = opt["ddconfig"].to_dict()
+    model = VQModelInterface(**opt)
+    if ckpt_path:
+        if not os.path.exists(ckpt_path):
+            raise FileNotFoundError(f"VQGAN checkpoint {ckpt_path} not found (set subnet.vq_model.ckpt_path, or null to skip)")
+        sd = torch.load(ckpt_path, map_location="cpu", weights_only=True)["state_dict"]
+        sd = {k: v for k, v in sd.items() if not k.startswith("loss.")}
+        model.load_state_dict(sd)
+    return model.to(device)
+
+
+def build_comp_model(opt):
+    opt = deepcopy(opt)
+    if _get(opt, "model"):
+        model_opt = deepcopy(dict(opt["model"]))
+        model_type = model_opt.pop("type")
+        return MODEL_REGISTRY.get(model_type)(opt, **model_opt)
+    raise ValueError('"model_type" key is not supported. Please use trainer.type')
+
+
+def build_trained_comp_model(opt, ckpt_path: str):
+    model = build_comp_model(opt)
+    model.load_learned_weight(ckpt_path=ckpt_path)
+    return model
+
+
+def _starts(size: int, stride: int, patch: int, pre_div: bool) -> List[int]:
+    """Window starts of the tiling branches (hyperprior_vic_model.py:197-213 / 420-436)."""
+    out = []
+    rng = range(size // stride + 1) if pre_div else range(0, size, stride)
+    for i in rng:
+        s = i * stride if pre_div else i
+        if s + patch < size:
+            out.append(s)
+        else:
+            out.append(size - patch)
+            break
+    return out
+
+
+class BaseModel(nn.Module):
+    def __init__(self, opt):
+        super().__init__()
+        self.opt = opt
+        self.device = _get(opt, "device", "cuda:0")
+        self.convert_img_range = bool(_get(opt, "convert_img_range_to_01", False))
+        if self.convert_img_range:
+            raise NotImplementedError("convert_img_range_to_01 is not used by the DC-VIC configs")
+        self._build_subnets()
+        self.stride = 64
+
+    def _build_subnets(self):
+        raise NotImplementedError()
+
+    # base_model.py:35-43
+    def img_preprocess(self, real_images: Tensor, is_train: bool = True) -> Tensor:
+        if is_train:
+            raise NotImplementedError("dc_vic_amd implements the inference path only")
+        out = real_images.to(self.device, dtype=torch.float32).contiguous()
+        return self.pad_images(out)
+
+    # base_model.py:45-57
+    def img_postprocess(self, *images: Tensor, size: Tuple[int, int], is_train: bool):
+        H, W = size
+        out = [ops.crop_clamp(img, H, W) for img in images]
+        return out[0] if len(out) == 1 else tuple(out)
+
+    def pad_images(self, *images: Tensor):
+        out = [self._pad_image(img, self.stride) for img in images]
+        return out[0] if len(out) == 1 else tuple(out)
+
+    @staticmethod
+    def _pad_image(x: Tensor, stride: int, mode: str = "reflect") -> Tensor:
+        _, _, H, W = x.shape
+        padW = int(np.ceil(W / stride) * stride - W)
+        padH = int(np.ceil(H / stride) * stride - H)
+        if padH == 0 and padW == 0:
+            return x
+        return ops.pad_reflect(x, padH, padW)
+
+    @staticmethod
+    def _crop_image(x: Tensor, H: int, W: int) -> Tensor:
+        return ops.crop(x, H, W)
+
+    def crop_images(self, *images: Tensor, size: Tuple[int, int]):
+        H, W = size
+        out = [self._crop_image(i, H, W) for i in images]
+        return out[0] if len(out) == 1 else tuple(out)
+
+    def load_state_dict(self, state_dict, strict: bool = True):
+        out = super().load_state_dict(state_dict, strict=strict)
+        for m in self.modules():
+            if hasattr(m, "invalidate_caches"):
+                m.invalidate_caches()
+        return out
+
+    # base_model.py:106-130
+    def load_learned_weight(self, ckpt_path: str, strict: bool = False) -> None:
+        ckpt = torch.load(ckpt_path, map_location="cpu", weights_only=True)
+        state_dict = ckpt["comp_model"]
+        new_sd = OrderedDict((k[7:] if k.startswith("module.") else k, v) for k, v in state_dict.items())
+        if not strict:
+            model_dict = self.state_dict()
+            model_dict.update({k: v for k, v in new_sd.items() if k in model_dict})
+            self.load_state_dict(model_dict)
+        else:
+            self.load_state_dict(new_sd)
+        for m in self.children():
+            if isinstance(m, EntropyBottleneck):
+                m.update(force=False)
+
+    def codec_setup(self):
+        raise NotImplementedError()
+
+
+@MODEL_REGISTRY.register()
+class HyperpriorVicModel(BaseModel):
+    def __init__(self, opt, gumbel_sampling: bool = False, gumbel_kwargs: Dict = {}, enc_vq_input: str = "norm_indices",
+                 enc_input_vq_recon: bool = False) -> None:
+        super().__init__(opt)
+        assert enc_vq_input in ["norm_indices", "onehot_indices", "long_indices"]
+        if enc_vq_input != "onehot_indices" or enc_input_vq_recon:
+            raise NotImplementedError("only enc_vq_input='onehot_indices' (the shipped configs) is built")
+        self.enc_vq_input = enc_vq_input
+        self.n_embed = self.vq_model.n_embed
+        self.model_stride, self.y_stride = 64, 16
+        self.to(self.device)
+
+    def _build_subnets(self) -> None:
+        sub = self.opt["subnet"]
+        self.encoder = build_subnet(sub["encoder"], "encoder")
+        self.decoder = build_subnet(sub["decoder"], "decoder")
+        self.hyperencoder = build_subnet(sub["hyperencoder"], "hyperencoder")
+        self.hyperdecoder = build_subnet(sub["hyperdecoder"], "hyperdecoder")
+        self.entropy_model_z = build_subnet(sub["entropy_model_z"], "entropy_model")
+        self.entropy_model_y = build_subnet(sub["entropy_model_y"], "entropy_model")
+        self.vq_estimator = build_vq_estimator(sub["vq_estimator"])
+        self.vq_model = build_pretrained_vq_model(sub["vq_model"], device=self.device)
+        self.vq_model.quantize.sane_index_shape = True
+        self.fusion_module = build_vq_fusion_module(sub["fusion_module"])
+
+    # hyperprior_vic_model.py:80-82
+    def likelihood_to_bit(self, likelihood: Tensor, num_pixel: int):
+        raise NotImplementedError("bits are reduced inside the rate kernels; see run_model / compress")
+
+    # ------------------------------------------------------------------ VQ encode (137-246)
+    def _vq_encode_split(self, real_images: Tensor) -> Tensor:
+        N, _, H, W = real_images.shape
+        stride, patch = SPLIT_STRIDE, SPLIT_WINDOW_SIZE
+        df = 2 ** (self.vq_model.encoder.num_resolutions - 1)
+        ndim = self.vq_model.embed_dim
+        lefts = _starts(W, stride, patch, True)
+        tops = _starts(H, stride, patch, True)
+        z_out = torch.zeros((N, ndim, H // df, W // df), dtype=torch.float32, device=real_images.device)
+        crop = torch.empty((N, real_images.shape[1], patch, patch), dtype=torch.float32, device=real_images.device)
+        for y0 in tops:
+            for x0 in lefts:
+                ops.copy_window(crop, real_images[:, :, y0:y0 + patch, x0:x0 + patch])
+                z = self.vq_model.encode(crop)
+                off = (stride // 2) // df
+                _x0, _y0 = x0 // df, y0 // df
+                l = _x0 + off if x0 > 0 else 0
+                t = _y0 + off if y0 > 0 else 0
+                r = _x0 + off + stride // df if x0 < lefts[-1] else W // df
+                b = _y0 + off + stride // df if y0 < tops[-1] else H // df
+                ops.copy_window(z_out[:, :, t:b, l:r], z[:, :, t - _y0:b - _y0, l - _x0:r - _x0])
+        return z_out
+
+    def vq_encode(self, real_images: Tensor, vq_indices: Optional[Tensor] = None, want_feat: bool = False):
+        """Returns (gt_vq_latent, gt_vq_indices[, feat = cat[latent, onehot]])."""
+        if vq_indices is not None:
+            raise NotImplementedError("pre-computed vq_indices are a training-dataset feature")
+        N, _, H, W = real_images.shape
+        _z = self._vq_encode_split(real_images) if max(H, W) > SPLIT_DECODE_RESOLUTION else self.vq_model.encode(real_images)
+        assert not (max(H, W) > 1024 and self.n_embed > 1024), "_vq_quantize_split is only needed for n_embed > 1024"
+        r = self.vq_model.quantize(_z, want_feat=want_feat)
+        if want_feat:
+            zq, _, (_, _, idx), feat = r
+            return zq, idx, feat
+        zq, _, (_, _, idx) = r
+        return zq, idx
+
+    def vq_indices_to_latent(self, indices: Tensor) -> Tensor:
+        e = self.vq_model.quantize.embedding(indices)          # [N, H, W, D]
+        return e.permute(0, 3, 1, 2).contiguous()
+
+    # ------------------------------------------------------------------ encoder (248-290)
+    def comp_encode(self, real_images: Tensor, gt_vq_latent: Tensor, gt_vq_indices: Tensor, enc_kwargs: Dict = {},
+                    feat: Optional[Tensor] = None) -> Tensor:
+        if feat is None:
+            _, _, feat = ops.vq_argmin(gt_vq_latent.contiguous(), self.vq_model.quantize.embedding.weight, want_zq=False, want_feat=True)
+        return self.encoder(real_images, feat, **enc_kwargs)
+
+    # ------------------------------------------------------------------ decode (276-288, 413-473)
+    def _decode(self, y_hat: Tensor, w: float, beta_rate, beta_vq, want_logits: bool = False):
+        N, _, yH, yW = y_hat.shape
+        cat_bufs = self.fusion_module.alloc_cat_buffers(N, 2 * yH, 2 * yW, y_hat.device)
+        feat_out = {k: cat_bufs[k][:, : self.fusion_module.fusion_modules[k].cond_ch] for k in cat_bufs}
+        feat_1, _ = self.decoder.get_feats(y_hat, beta_1=beta_rate, beta_2=beta_vq, feat_out=feat_out)
+        _, logits = self.vq_estimator(feat_1)
+        pq = self.vq_model.post_quant_conv
+        idx, lat = ops.argmax_lut(logits, self.vq_model.quantize.embedding.weight, pq.weight.reshape(pq.out_channels, -1).contiguous(), pq.bias)
+        img = self.fusion_module(lat, None, self.vq_model.decoder, w=w, cat_bufs=cat_bufs)
+        if want_logits:
+            return img, idx, logits
+        return img, idx
+
+    def decode_split(self, y_hat: Tensor, fuse_w: float, **kwargs) -> Tensor:
+        N, _, yH, yW = y_hat.shape
+        df = 16
+        stride, patch = SPLIT_STRIDE // df, SPLIT_WINDOW_SIZE // df
+        lefts = _starts(yW, stride, patch, False)
+        tops = _starts(yH, stride, patch, False)
+        out = torch.full((N, 3, yH * df, yW * df), -100.0, dtype=torch.float32, device=y_hat.device)
+        crop = torch.empty((N, y_hat.shape[1], patch, patch), dtype=torch.float32, device=y_hat.device)
+        for y0 in tops:
+            for x0 in lefts:
+                ops.copy_window(crop, y_hat[:, :, y0:y0 + patch, x0:x0 + patch])
+                o, _ = self._decode(crop, w=fuse_w, **kwargs)
+                off = (stride // 2) * df
+                _x0, _y0 = x0 * df, y0 * df
+                l = _x0 + off if x0 > 0 else 0
+                t = _y0 + off if y0 > 0 else 0
+                r = _x0 + off + stride * df if x0 < lefts[-1] else yW * df
+                b = _y0 + off + stride * df if y0 < tops[-1] else yH * df
+                ops.copy_window(out[:, :, t:b, l:r], o[:, :, t - _y0:b - _y0, l - _x0:r - _x0])
+        return out
+
+    def codec_setup(self):
+        """hyperprior_dc_vic_model.py:65-89: build the integer CDF tables; strides are properties of the
+        architecture (4 stride-2 encoder stages -> y_stride 16, 2 more in the hyper-encoder -> 64)."""
+        self.entropy_model_z.update(force=True)
+        self.entropy_model_y.update_scale_table(get_scale_table(), force=True)
+        self.yC = self.encoder.conv4.out_channels
+        self.zC = self.hyperencoder.conv3.out_channels
+        self.y_stride = 2 ** self.encoder.num_downscale
+        self.model_stride = self.y_stride * 2 ** self.hyperencoder.n_downsampling_layers
+
+
+@MODEL_REGISTRY.register()
+class HyperpriorDualCondVicModel(HyperpriorVicModel):
+    def __init__(self, opt, gumbel_sampling: bool = False, gumbel_kwargs: Dict = {}, enc_vq_input: str = "norm_indices",
+                 enc_input_vq_recon: bool = False, num_beta_levels: int = 100, use_selected_beta_pairs: bool = False,
+                 selected_beta_rate: Optional[List[float]] = None, selected_beta_vq: Optional[List[float]] = None) -> None:
+        super().__init__(opt, gumbel_sampling=gumbel_sampling, gumbel_kwargs=gumbel_kwargs, enc_vq_input=enc_vq_input,
+                         enc_input_vq_recon=enc_input_vq_recon)
+        self.max_beta_rate = float(opt["subnet"]["decoder"]["max_beta_1"])
+        self.max_beta_vq = float(opt["subnet"]["decoder"]["max_beta_2"])
+        self.num_beta_levels = num_beta_levels
+        self.use_selected_beta_pairs = use_selected_beta_pairs
+        self.selected_beta_rate = list(selected_beta_rate) if selected_beta_rate is not None else None
+        self.selected_beta_vq = list(selected_beta_vq) if selected_beta_vq is not None else None
+        if self.use_selected_beta_pairs:
+            assert isinstance(self.selected_beta_rate, list) and isinstance(self.selected_beta_vq, list)
+            assert len(self.selected_beta_rate) == len(self.selected_beta_vq)
+
+    # ------------------------------------------------------------------ entropy stage
+    def _entropy_encode_side(self, y: Tensor, want_symbols: bool):
+        """hyper-encoder -> z symbols / z_hat / z bits -> hyper-decoder -> CHARM (all on the GPU)."""
+        N = y.shape[0]
+        z = self.hyperencoder(y)
+        bits_z = torch.zeros(N, dtype=torch.float32, device=y.device)
+        bits_y = torch.zeros(N, dtype=torch.float32, device=y.device)
+        z_hat = torch.empty_like(z)
+        z_lik = torch.empty_like(z)
+        z_sym = torch.empty(z.shape, dtype=torch.int32, device=y.device) if want_symbols else None
+        ops.eb_rate(z, self.entropy_model_z.packs(), z_hat, z_sym, z_lik, bits_z)
+        hyper_out = self.hyperdecoder(z_hat)
+        r = self._run_context(y, hyper_out, want_symbols, bits_y)
+        return dict(z=z, z_hat=z_hat, z_likelihood=z_lik, z_symbols=z_sym, bits_z=bits_z, bits_y=bits_y, hyper_out=hyper_out, **r)
+
+    def _run_context(self, y, hyper_out, want_symbols, bits_y):
+        raise NotImplementedError("only the CHARM variant (HyperpriorCharmDualCondVicModel) is shipped")
+
+    # ------------------------------------------------------------------ run_model (112-118, 208-274)
+    @torch.no_grad()
+    def run_model(self, real_images: Tensor, is_train: bool = False, beta_rate=None, beta_vq=None, vq_indices=None,
+                  fusion_w: Optional[float] = None, **unused) -> Dict:
+        if is_train:
+            raise NotImplementedError("dc_vic_amd implements the inference path only")
+        if beta_rate is None or beta_vq is None:
+            raise ValueError('"beta_rate" and "beta_vq" must be specified if is_train=False')
+        N, _, H, W = real_images.shape
+        x = self.img_preprocess(real_images, is_train=False)
+        gt_vq_latent, gt_vq_indices, feat = self.vq_encode(x, vq_indices, want_feat=True)
+        y = self.comp_encode(x, gt_vq_latent, gt_vq_indices, enc_kwargs=dict(beta_1=beta_rate, beta_2=beta_vq), feat=feat)
+        e = self._entropy_encode_side(y, want_symbols=False)
+        y_hat = e["y_hat"]
+        w = 1.0
+        if max(x.shape[2:]) > SPLIT_DECODE_RESOLUTION:
+            fake = self.decode_split(y_hat, w, beta_rate=beta_rate, beta_vq=beta_vq)
+            out_idx = torch.zeros_like(gt_vq_indices)
+            logits = None
+            vq_acc = 0.0
+        else:
+            fake, out_idx, logits = self._decode(y_hat, w, beta_rate, beta_vq, want_logits=True)
+            vq_acc = float((out_idx.cpu() == gt_vq_indices.cpu()).float().mean())
+        num_pixel = N * H * W
+        bits = (e["bits_y"].double().sum() + e["bits_z"].double().sum()).item()
+        bpp = bits / num_pixel
+        fake_c = ops.crop_clamp(fake, H, W)
+        real_c = ops.crop_clamp(x, H, W)
+        return dict(real_images=real_c, fake_images=fake_c, y_hat=y_hat, z_hat=e["z_hat"], bpp=bpp, qbpp=bpp,
+                    y_likelihood=e["y_likelihood"], z_likelihood=e["z_likelihood"], y_q_likelihood=e["y_likelihood"],
+                    z_q_likelihood=e["z_likelihood"], gt_vq_latent=gt_vq_latent, gt_vq_indices=gt_vq_indices,
+                    out_vq_indices=out_idx, out_vq_logits=logits, vq_accuracy=vq_acc, beta_rate=beta_rate, beta_vq=beta_vq,
+                    bits_per_image=(e["bits_y"] + e["bits_z"]))
+
+    # ------------------------------------------------------------------ compress (330-376)
+    @torch.no_grad()
+    def compress_batch(self, real_images: Tensor, quality_ind: int) -> Dict:
+        """N images of one size -> N bitstreams (`string_lists[i] = [header, z_str, y_str]`)."""
+        beta_rate = self.selected_beta_rate[quality_ind]
+        beta_vq = self.selected_beta_vq[quality_ind]
+        N, _, H, W = real_images.shape
+        x = self.img_preprocess(real_images, is_train=False)
+        gt_vq_latent, gt_vq_indices, feat = self.vq_encode(x, None, want_feat=True)
+        y = self.comp_encode(x, gt_vq_latent, gt_vq_indices, enc_kwargs=dict(beta_1=beta_rate, beta_2=beta_vq), feat=feat)
+        e = self._entropy_encode_side(y, want_symbols=True)
+        y_hat = e["y_hat"]
+        maxabs = ops.absmax(y_hat)
+        thr = host_threads()
+        # one D2H per array; the rANS streams are independent -> host threads
+        z_sym = e["z_symbols"].reshape(N, -1).cpu().numpy()
+        y_sym = e["symbols"].reshape(N, -1).cpu().numpy()
+        y_idx = e["indexes"].reshape(N, -1).cpu().numpy()
+        maxabs_h = maxabs.cpu().numpy()
+        bits_y = e["bits_y"].cpu().numpy().astype(np.float64)
+        bits_z = e["bits_z"].cpu().numpy().astype(np.float64)
+        zC, zH, zW = e["z"].shape[1:]
+        z_strs = self.entropy_model_z.tables().encode(z_sym, self.entropy_model_z._channel_indexes(N, zH * zW), threads=thr)
+        y_strs = self.entropy_model_y.tables().encode(y_sym, y_idx, threads=thr)
+        hh = HeaderHandler()
+        string_lists = [[hh.encode((H, W), float(maxabs_h[i]), quality_ind), z_strs[i], y_strs[i]] for i in range(N)]
+        return dict(string_lists=string_lists, z_hat=e["z_hat"], y_hat=y_hat, z_likelihood=e["z_likelihood"],
+                    y_likelihood=e["y_likelihood"], vq_indices=gt_vq_indices, y=y, z=e["z"], y_symbols=e["symbols"],
+                    y_indexes=e["indexes"], z_symbols=e["z_symbols"],
+                    pred_y_bit=bits_y, pred_z_bit=bits_z, pred_y_bpp=bits_y / (H * W), pred_z_bpp=bits_z / (H * W))
+
+    @torch.no_grad()
+    def compress(self, real_images: Tensor, quality_ind: Optional[int], vq_indices=None) -> Dict:
+        N = real_images.shape[0]
+        assert N == 1, f"In compress mode, batch_size must be 1, but {N}"
+        r = self.compress_batch(real_images, quality_ind)
+        return {
+            "string_list": r["string_lists"][0], "z_hat": r["z_hat"], "y_hat": r["y_hat"],
+            "z_likelihood": r["z_likelihood"], "y_likelihood": r["y_likelihood"],
+            "pred_y_bit": float(r["pred_y_bit"][0]), "pred_y_bpp": float(r["pred_y_bpp"][0]),
+            "pred_z_bit": float(r["pred_z_bit"][0]), "pred_z_bpp": float(r["pred_z_bpp"][0]),
+            "vq_indices": r["vq_indices"], "y_symbols": r["y_symbols"], "y_indexes": r["y_indexes"], "z_symbols": r["z_symbols"],
+        }
+
+    # ------------------------------------------------------------------ decompress (389-440)
+    def _decompress_entropy(self, z_strs: Sequence[bytes], y_strs: Sequence[bytes], zH: int, zW: int):
+        raise NotImplementedError("only the CHARM variant is shipped")
+
+    @torch.no_grad()
+    def decompress_batch(self, string_lists: Sequence[Sequence[bytes]], want_u8: bool = False):
+        """All streams must carry the same (H, W, quality).  Returns (images, z_hat, y_hat[, uint8 HWC])."""
+        hh = HeaderHandler()
+        heads = []
+        for sl in string_lists:
+            assert len(sl) == 3, f"String list length should be 3 (header, z, and y), but got {len(sl)}"
+            heads.append(hh.decode(sl[0]))
+        H, W = heads[0]["img_size"]
+        q = heads[0]["quality_ind"]
+        for h in heads:
+            if h["img_size"] != (H, W) or h["quality_ind"] != q:
+                raise ValueError("decompress_batch needs equal image sizes and quality (group the streams first)")
+        padH = int(np.ceil(H / self.model_stride)) * self.model_stride
+        padW = int(np.ceil(W / self.model_stride)) * self.model_stride
+        zH, zW = padH // self.model_stride, padW // self.model_stride
+        beta_rate, beta_vq = self.selected_beta_rate[q], self.selected_beta_vq[q]
+        y_hat, z_hat = self._decompress_entropy([sl[1] for sl in string_lists], [sl[2] for sl in string_lists], zH, zW)
+        w = 1.0
+        if max(H, W) > SPLIT_DECODE_RESOLUTION:
+            fake = self.decode_split(y_hat, w, beta_rate=beta_rate, beta_vq=beta_vq)
+        else:
+            fake, _ = self._decode(y_hat, w, beta_rate, beta_vq)
+        if want_u8:
+            img, u8 = ops.crop_clamp(fake, H, W, want_u8=True)
+            return img, z_hat, y_hat, u8
+        return ops.crop_clamp(fake, H, W), z_hat, y_hat
+
+    @torch.no_grad()
+    def decompress(self, string_list: List) -> Tuple[Tensor, Tensor, Tensor]:
+        assert len(string_list) == 3, f"String list length should be 3 (header, z, and y), but got {len(string_list)}"
+        return self.decompress_batch([string_list])
+
+
+@MODEL_REGISTRY.register()
+class HyperpriorCharmDualCondVicModel(HyperpriorDualCondVicModel):
+    def _build_subnets(self) -> None:
+        super()._build_subnets()
+        self.context_model = build_subnet(self.opt["subnet"]["context_model"], "context_model")
+
+    def _run_context(self, y, hyper_out, want_symbols, bits_y):
+        return self.context_model.run(y, hyper_out, self.entropy_model_y, want_likelihood=True, want_symbols=want_symbols, bits_out=bits_y)
+
+    # hyperprior_charm_dc_vic_model.py:24-56
+    def estimate_entropy(self, y: Tensor, is_train: bool = False):
+        if is_train:
+            raise NotImplementedError("dc_vic_amd implements the inference path only")
+        e = self._entropy_encode_side(y, want_symbols=False)
+        return {"quantized_code": {"y": e["y_hat"], "z": e["z_hat"]}, "latent_code": {"y": y, "z": e["z"]},
+                "likelihoods": {"y": e["y_likelihood"], "z": e["z_likelihood"]},
+                "q_likelihoods": {"y": e["y_likelihood"], "z": e["z_likelihood"]}}
+
+    # hyperprior_charm_dc_vic_model.py:83-91
+    def _decompress_entropy(self, z_strs, y_strs, zH: int, zW: int):
+        z_hat = self.entropy_model_z.decompress(list(z_strs), (zH, zW))
+        hyper_out = self.hyperdecoder(z_hat)
+        y_hat, _ = self.context_model.forward_decompress(list(y_strs), hyper_out, self.entropy_model_y)
+        return y_hat, z_hat

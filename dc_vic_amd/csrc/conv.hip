@@ -1,0 +1,416 @@
+// conv.hip -- implicit-GEMM convolution family on the fp32 MFMA (v_mfma_f32_32x32x2_f32), gfx950.
+//
+// One kernel template covers every Conv2d / ConvTranspose2d phase / upsample+conv on the DC-VIC path
+// (see include/dcvic.h for the reference operators it replaces).
+//
+// GEMM view:   D[co][pixel] = sum_{ci,tap} Wt[tap][ci][co] * X[ci][pixel + tap]
+//   A operand = weights (rows = output channels), B operand = input pixels (cols), so that the
+//   accumulator's lane axis is the pixel axis and NCHW stores are 128-B row segments.
+// Data movement per workgroup (256 threads = 4 waves) and K-chunk of 8 input channels:
+//   * the input PATCH (tile + halo, all taps) of the 8 channels is staged once into LDS, zero padded
+//     (coalesced reads of NCHW rows), and re-used by every tap -> each input element is read from
+//     HBM/L2 once per output-channel tile instead of once per tap;
+//   * the pre-packed weight slab [tap][8][TC] is a linear float4 copy into LDS;
+//   * every wave then issues MT x NT MFMA 32x32x2 per (tap, channel pair) with operands fetched by
+//     conflict-free ds_read_b32 (consecutive lanes -> consecutive words).
+// The fp32 MFMA is a k-ordered fmaf chain, so the reduction order of an output element is
+// (chunk asc, tap asc, channel asc) for every tile configuration, grid and batch size:
+// results are deterministic and batch-invariant (needed for encoder/decoder agreement).
+#include "common.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#define KC 8
+#define MAXSLOT 6
+#define NTHREADS 256
+
+struct ConvKArgs {
+    int Cin, Cout, T, stride, ups;
+    int N, H, W, Hout, Wout, Hfull, Wfull, osy, osx, ooy, oox;
+    int n_src;
+    const float* src[DCVIC_MAX_SRC];
+    int srcC[DCVIC_MAX_SRC];
+    long long src_bs[DCVIC_MAX_SRC];
+    float* out;
+    long long out_bs;
+    const float* bias;
+    int act;
+    const float* res;
+    long long res_bs;
+    const float* affs;
+    const float* afft;
+    long long aff_bs;
+    const float* wp;
+    int tap[DCVIC_MAX_TAPS];  // (dy & 0xffff) | (dx << 16)
+    int TWlog, tiles_x, tiles_y;
+    int PH, PW, plane, dy_min, dx_min;
+    int TG, n_chunks, n_cotiles;
+};
+
+template <int MT, int NT, int WM, int WN>
+__global__ __launch_bounds__(NTHREADS, 2) void conv_mfma_kernel(const ConvKArgs K) {
+    constexpr int TC = WM * MT * 32;
+    constexpr int P = WN * NT * 32;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* Xs = smem;                                  // [KC][plane]
+    float* Ws = smem + ((KC * K.plane + 3) & ~3);      // [TG][KC][TC]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int lane_k = lane >> 5, lane_j = lane & 31;
+
+    // block -> (n, tile_y, tile_x, cotile); cotile fastest so that co-tiles of one patch run together
+    int b = blockIdx.x;
+    const int cotile = b % K.n_cotiles; b /= K.n_cotiles;
+    const int tile_x = b % K.tiles_x; b /= K.tiles_x;
+    const int tile_y = b % K.tiles_y; b /= K.tiles_y;
+    const int n = b;
+    const int TW = 1 << K.TWlog;
+    const int TH = P >> K.TWlog;
+    const int oy0 = tile_y * TH, ox0 = tile_x * TW;
+
+    // patch origin in input coordinates
+    int iy0, ix0;
+    if (K.ups) { iy0 = (oy0 + K.dy_min) >> 1; ix0 = (ox0 + K.dx_min) >> 1; }
+    else { iy0 = oy0 * K.stride + K.dy_min; ix0 = ox0 * K.stride + K.dx_min; }
+
+    // per-thread patch slots (identical for every channel / chunk)
+    int goff[MAXSLOT];
+#pragma unroll
+    for (int s = 0; s < MAXSLOT; ++s) {
+        const int r = tid + s * NTHREADS;
+        int g = -1;
+        if (r < K.plane) {
+            const int py = r / K.PW, px = r - py * K.PW;
+            const int iy = iy0 + py, ix = ix0 + px;
+            if (iy >= 0 && iy < K.H && ix >= 0 && ix < K.W) g = iy * K.W + ix;
+        }
+        goff[s] = g;
+    }
+
+    // per-lane pixel coordinates of each B fragment
+    int pty[NT], ptx[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const int p = (wn * NT + nt) * 32 + lane_j;
+        pty[nt] = p >> K.TWlog;
+        ptx[nt] = p & (TW - 1);
+    }
+
+    f32x16 acc[MT][NT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
+
+    const long long HW = (long long)K.H * K.W;
+    const float* wbase = K.wp + (long long)cotile * K.n_chunks * K.T * (KC * TC);
+
+    for (int chunk = 0; chunk < K.n_chunks; ++chunk) {
+        // ---- stage the input patch of channels [c0, c0+8)
+        const int c0 = chunk * KC;
+#pragma unroll
+        for (int k = 0; k < KC; ++k) {
+            int c = c0 + k;
+            const float* p = nullptr;
+            if (c < K.Cin) {
+                int si = 0;
+                if (c >= K.srcC[0]) { c -= K.srcC[0]; si = 1; if (c >= K.srcC[1]) { c -= K.srcC[1]; si = 2; } }
+                p = K.src[si] + (long long)n * K.src_bs[si] + (long long)c * HW;
+            }
+#pragma unroll
+            for (int s = 0; s < MAXSLOT; ++s) {
+                const int r = tid + s * NTHREADS;
+                if (r < K.plane) {
+                    float v = 0.f;
+                    if (p != nullptr && goff[s] >= 0) v = p[goff[s]];
+                    Xs[k * K.plane + r] = v;
+                }
+            }
+        }
+        for (int tg = 0; tg < K.T; tg += K.TG) {
+            const int ntap = min(K.TG, K.T - tg);
+            // ---- stage the weight slab [ntap][KC][TC] (linear copy)
+            {
+                const float4* wsrc = reinterpret_cast<const float4*>(wbase + ((long long)chunk * K.T + tg) * (KC * TC));
+                float4* wdst = reinterpret_cast<float4*>(Ws);
+                const int nvec = ntap * (KC * TC / 4);
+                for (int i = tid; i < nvec; i += NTHREADS) wdst[i] = wsrc[i];
+            }
+            __syncthreads();
+            for (int tt = 0; tt < ntap; ++tt) {
+                const int tp = K.tap[tg + tt];
+                const int dy = (int)(short)(tp & 0xffff), dx = tp >> 16;
+                int boff[NT];
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    int row, col;
+                    if (K.ups) {
+                        row = ((oy0 + pty[nt] + dy) >> 1) - iy0;
+                        col = ((ox0 + ptx[nt] + dx) >> 1) - ix0;
+                    } else {
+                        row = pty[nt] * K.stride + dy - K.dy_min;
+                        col = ptx[nt] * K.stride + dx - K.dx_min;
+                    }
+                    boff[nt] = row * K.PW + col + lane_k * K.plane;
+                }
+                const float* As = Ws + (tt * KC + lane_k) * TC + wm * (MT * 32) + lane_j;
+#pragma unroll
+                for (int ks = 0; ks < KC / 2; ++ks) {
+                    float a[MT], bb[NT];
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt) a[mt] = As[(2 * ks) * TC + mt * 32];
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) bb[nt] = Xs[boff[nt] + (2 * ks) * K.plane];
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                        for (int nt = 0; nt < NT; ++nt)
+                            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mt], bb[nt], acc[mt][nt], 0, 0, 0);
+                }
+            }
+            __syncthreads();
+        }
+    }
+
+    // ---- epilogue: bias -> act -> (+res) -> (affine) -> store
+    const long long HWo = (long long)K.Hfull * K.Wfull;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const int oy = oy0 + pty[nt], ox = ox0 + ptx[nt];
+        if (oy >= K.Hout || ox >= K.Wout) continue;
+        const long long pix = (long long)(oy * K.osy + K.ooy) * K.Wfull + (ox * K.osx + K.oox);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = cotile * TC + (wm * MT + mt) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lane_k;
+                if (co >= K.Cout) continue;
+                float v = acc[mt][nt][r];
+                if (K.bias) v += K.bias[co];
+                v = dcvic_act(v, K.act);
+                if (K.res) v += K.res[(long long)n * K.res_bs + (long long)co * HWo + pix];
+                if (K.affs) {
+                    const long long ai = (long long)n * K.aff_bs + co;
+                    v = v * (1.f + K.affs[ai]) + K.afft[ai];
+                }
+                K.out[(long long)n * K.out_bs + (long long)co * HWo + pix] = v;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// weight packing: [cotile][chunk][tap][k][TC]
+__global__ void conv_pack_kernel(const float* __restrict__ w, float* __restrict__ wp, int Cin, int Cout, int T,
+                                 int KH, int KW, int transposed, int TC, int n_chunks, long long total,
+                                 const int* __restrict__ tapk) {
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    long long r = i;
+    const int col = r % TC; r /= TC;
+    const int k = r % KC; r /= KC;
+    const int t = r % T; r /= T;
+    const int chunk = r % n_chunks; r /= n_chunks;
+    const int cotile = (int)r;
+    const int co = cotile * TC + col, ci = chunk * KC + k;
+    float v = 0.f;
+    if (co < Cout && ci < Cin) {
+        const int ky = tapk[2 * t], kx = tapk[2 * t + 1];
+        const long long idx = transposed ? (((long long)ci * Cout + co) * KH + ky) * KW + kx
+                                         : (((long long)co * Cin + ci) * KH + ky) * KW + kx;
+        v = w[idx];
+    }
+    wp[i] = v;
+}
+
+// ------------------------------------------------------------------------------------------------
+// tile configurations
+struct TileCfg { int MT, NT, WM, WN; };
+static const TileCfg kCfgs[] = {
+    {2, 4, 2, 2},  // 0: TC 128, P 256
+    {2, 2, 1, 4},  // 1: TC 64,  P 256
+    {1, 2, 1, 4},  // 2: TC 32,  P 256
+    {3, 2, 1, 4},  // 3: TC 96,  P 256
+};
+static inline int cfg_TC(int c) { return kCfgs[c].WM * kCfgs[c].MT * 32; }
+static inline int cfg_P(int c) { return kCfgs[c].WN * kCfgs[c].NT * 32; }
+
+static int choose_cfg(int Cout) {
+    if (Cout <= 32) return 2;
+    if (Cout <= 64) return 1;
+    if (Cout == 96 || Cout == 192) return 3;
+    if (Cout % 128 == 0 || Cout > 192) return 0;
+    return 1;
+}
+
+extern "C" int dcvic_conv_desc_init(dcvic_conv_desc* d, int Cin, int Cout, int KH, int KW, int stride, int pad_t,
+                                    int pad_l, int upsample) {
+    DCVIC_CHECK_ARG(d && Cin > 0 && Cout > 0, "conv_desc_init: bad channels");
+    DCVIC_CHECK_ARG(KH >= 1 && KW >= 1 && KH * KW <= DCVIC_MAX_TAPS, "conv_desc_init: kernel %dx%d unsupported", KH, KW);
+    DCVIC_CHECK_ARG(stride == 1 || stride == 2, "conv_desc_init: stride %d unsupported", stride);
+    DCVIC_CHECK_ARG(!(upsample && stride != 1), "conv_desc_init: upsample needs stride 1");
+    memset(d, 0, sizeof(*d));
+    d->Cin = Cin; d->Cout = Cout; d->KH = KH; d->KW = KW; d->stride = stride; d->upsample = upsample;
+    d->T = KH * KW;
+    for (int ky = 0; ky < KH; ++ky)
+        for (int kx = 0; kx < KW; ++kx) {
+            const int t = ky * KW + kx;
+            d->tap_ky[t] = (int8_t)ky; d->tap_kx[t] = (int8_t)kx;
+            d->tap_dy[t] = (int8_t)(ky - pad_t); d->tap_dx[t] = (int8_t)(kx - pad_l);
+        }
+    d->cfg = choose_cfg(Cout);
+    return DCVIC_OK;
+}
+
+extern "C" int dcvic_convT_phase_desc(dcvic_conv_desc* d, int Cin, int Cout, int k, int py, int px) {
+    DCVIC_CHECK_ARG(d && Cin > 0 && Cout > 0, "convT_phase_desc: bad channels");
+    memset(d, 0, sizeof(*d));
+    d->Cin = Cin; d->Cout = Cout; d->KH = k; d->KW = k; d->stride = 1; d->upsample = 0; d->transposed_weight = 1;
+    int t = 0;
+    if (k == 3) {
+        // ConvTranspose2d(k3,s1,p1): out[oy] += in[iy] * w[ky], oy = iy - 1 + ky  =>  dy = 1 - ky
+        DCVIC_CHECK_ARG(py == 0 && px == 0, "convT k3 has a single phase");
+        for (int ky = 0; ky < 3; ++ky)
+            for (int kx = 0; kx < 3; ++kx) {
+                d->tap_ky[t] = (int8_t)ky; d->tap_kx[t] = (int8_t)kx;
+                d->tap_dy[t] = (int8_t)(1 - ky); d->tap_dx[t] = (int8_t)(1 - kx); ++t;
+            }
+    } else if (k == 5) {
+        // ConvTranspose2d(k5,s2,p2,op1): oy = 2*iy - 2 + ky.  For oy = 2m + py: ky = py (mod 2), iy = m + (py + 2 - ky)/2
+        DCVIC_CHECK_ARG((py == 0 || py == 1) && (px == 0 || px == 1), "convT k5 phases are 0/1");
+        for (int ky = py; ky < 5; ky += 2)
+            for (int kx = px; kx < 5; kx += 2) {
+                d->tap_ky[t] = (int8_t)ky; d->tap_kx[t] = (int8_t)kx;
+                d->tap_dy[t] = (int8_t)((py + 2 - ky) / 2); d->tap_dx[t] = (int8_t)((px + 2 - kx) / 2); ++t;
+            }
+    } else {
+        DCVIC_CHECK_ARG(false, "convT kernel %d unsupported", k);
+    }
+    d->T = t;
+    d->cfg = choose_cfg(Cout);
+    return DCVIC_OK;
+}
+
+static inline int n_chunks_of(const dcvic_conv_desc* d) { return (d->Cin + KC - 1) / KC; }
+static inline int n_cotiles_of(const dcvic_conv_desc* d) { return (d->Cout + cfg_TC(d->cfg) - 1) / cfg_TC(d->cfg); }
+
+extern "C" size_t dcvic_conv_packed_bytes(const dcvic_conv_desc* d) {
+    if (!d || d->cfg < 0 || d->cfg > 3) return 0;
+    return (size_t)n_cotiles_of(d) * n_chunks_of(d) * d->T * KC * cfg_TC(d->cfg) * sizeof(float);
+}
+
+extern "C" int dcvic_conv_pack_f32(const dcvic_conv_desc* d, const float* w, float* packed, void* stream) {
+    DCVIC_CHECK_ARG(d && w && packed, "conv_pack: null pointer");
+    const int TC = cfg_TC(d->cfg);
+    const long long total = (long long)n_cotiles_of(d) * n_chunks_of(d) * d->T * KC * TC;
+    // the tap->kernel index table travels through a tiny device buffer owned by the caller's stream
+    int h_tapk[2 * DCVIC_MAX_TAPS];
+    for (int t = 0; t < d->T; ++t) { h_tapk[2 * t] = d->tap_ky[t]; h_tapk[2 * t + 1] = d->tap_kx[t]; }
+    int* d_tapk = nullptr;
+    if (hipMalloc(&d_tapk, sizeof(h_tapk)) != hipSuccess) { dcvic_set_error("conv_pack: hipMalloc"); return DCVIC_ELAUNCH; }
+    hipMemcpyAsync(d_tapk, h_tapk, sizeof(int) * 2 * d->T, hipMemcpyHostToDevice, (hipStream_t)stream);
+    conv_pack_kernel<<<dcvic_cdiv(total, 256), 256, 0, (hipStream_t)stream>>>(w, packed, d->Cin, d->Cout, d->T, d->KH, d->KW,
+                                                                        d->transposed_weight, TC, n_chunks_of(d), total, d_tapk);
+    hipError_t e = hipGetLastError();
+    hipStreamSynchronize((hipStream_t)stream);  // pack is a load-time operation; keeps d_tapk's lifetime simple
+    hipFree(d_tapk);
+    if (e != hipSuccess) { dcvic_set_error("conv_pack: %s", hipGetErrorString(e)); return DCVIC_ELAUNCH; }
+    return DCVIC_OK;
+}
+
+template <int MT, int NT, int WM, int WN>
+static int launch_cfg(const ConvKArgs& K, int blocks, size_t lds, hipStream_t st) {
+    static bool attr_set = false;
+    auto kern = conv_mfma_kernel<MT, NT, WM, WN>;
+    if (!attr_set) {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set = true;
+    }
+    kern<<<blocks, NTHREADS, lds, st>>>(K);
+    DCVIC_CHECK_LAUNCH("conv2d");
+    return DCVIC_OK;
+}
+
+extern "C" int dcvic_conv2d_f32(const dcvic_conv_desc* d, const float* packed, const dcvic_conv_io* io, void* stream) {
+    DCVIC_CHECK_ARG(d && packed && io && io->out, "conv2d: null pointer");
+    DCVIC_CHECK_ARG(io->n_src >= 1 && io->n_src <= DCVIC_MAX_SRC, "conv2d: n_src %d", io->n_src);
+    int csum = 0;
+    for (int i = 0; i < io->n_src; ++i) {
+        DCVIC_CHECK_ARG(io->src[i].ptr && io->src[i].C > 0, "conv2d: source %d empty", i);
+        DCVIC_CHECK_ARG(io->src[i].batch_stride >= (long long)io->src[i].C * io->H * io->W, "conv2d: source %d batch stride too small", i);
+        csum += io->src[i].C;
+    }
+    DCVIC_CHECK_ARG(csum == d->Cin, "conv2d: sources carry %d channels, layer expects %d", csum, d->Cin);
+    DCVIC_CHECK_ARG(io->N > 0 && io->H > 0 && io->W > 0 && io->Hout > 0 && io->Wout > 0, "conv2d: bad sizes");
+    DCVIC_CHECK_ARG(io->osy >= 1 && io->osx >= 1 && io->ooy >= 0 && io->oox >= 0, "conv2d: bad output scatter");
+    DCVIC_CHECK_ARG((io->Hout - 1) * io->osy + io->ooy < io->Hfull && (io->Wout - 1) * io->osx + io->oox < io->Wfull,
+                    "conv2d: output scatter exceeds the output plane");
+    DCVIC_CHECK_ARG(io->out_batch_stride >= (long long)d->Cout * io->Hfull * io->Wfull, "conv2d: out batch stride too small");
+    DCVIC_CHECK_ARG((long long)io->H * io->W < (1ll << 30) && (long long)io->Hfull * io->Wfull < (1ll << 30), "conv2d: plane too large");
+    DCVIC_CHECK_ARG(!io->res || io->res_batch_stride >= (long long)d->Cout * io->Hfull * io->Wfull, "conv2d: res batch stride too small");
+    DCVIC_CHECK_ARG((io->aff_scale == nullptr) == (io->aff_shift == nullptr), "conv2d: affine needs both scale and shift");
+
+    ConvKArgs K;
+    memset(&K, 0, sizeof(K));
+    K.Cin = d->Cin; K.Cout = d->Cout; K.T = d->T; K.stride = d->stride; K.ups = d->upsample;
+    K.N = io->N; K.H = io->H; K.W = io->W; K.Hout = io->Hout; K.Wout = io->Wout; K.Hfull = io->Hfull; K.Wfull = io->Wfull;
+    K.osy = io->osy; K.osx = io->osx; K.ooy = io->ooy; K.oox = io->oox;
+    K.n_src = io->n_src;
+    for (int i = 0; i < DCVIC_MAX_SRC; ++i) {
+        if (i < io->n_src) { K.src[i] = io->src[i].ptr; K.srcC[i] = io->src[i].C; K.src_bs[i] = io->src[i].batch_stride; }
+        else { K.src[i] = io->src[0].ptr; K.srcC[i] = 1 << 30; K.src_bs[i] = 0; }
+    }
+    // sources after the last real one are never selected: make the last real one unbounded
+    K.out = io->out; K.out_bs = io->out_batch_stride; K.bias = io->bias; K.act = io->act;
+    K.res = io->res; K.res_bs = io->res_batch_stride; K.affs = io->aff_scale; K.afft = io->aff_shift; K.aff_bs = io->aff_batch_stride;
+    K.wp = packed;
+    int dy_min = 127, dy_max = -128, dx_min = 127, dx_max = -128;
+    for (int t = 0; t < d->T; ++t) {
+        K.tap[t] = ((int)d->tap_dy[t] & 0xffff) | ((int)d->tap_dx[t] << 16);
+        dy_min = min(dy_min, (int)d->tap_dy[t]); dy_max = max(dy_max, (int)d->tap_dy[t]);
+        dx_min = min(dx_min, (int)d->tap_dx[t]); dx_max = max(dx_max, (int)d->tap_dx[t]);
+    }
+    K.dy_min = dy_min; K.dx_min = dx_min;
+    const int cfg = d->cfg;
+    DCVIC_CHECK_ARG(cfg >= 0 && cfg <= 3, "conv2d: bad cfg %d", cfg);
+    const int TC = cfg_TC(cfg), P = cfg_P(cfg);
+    // tile width: the largest power of two <= 32 that does not exceed the (rounded-up) output width
+    int TWlog = 5;
+    while (TWlog > 2 && (1 << TWlog) > io->Wout && (1 << (TWlog - 1)) >= io->Wout) --TWlog;
+    const int TW = 1 << TWlog, TH = P / TW;
+    K.TWlog = TWlog;
+    K.tiles_x = (io->Wout + TW - 1) / TW;
+    K.tiles_y = (io->Hout + TH - 1) / TH;
+    if (d->upsample) {
+        K.PH = TH / 2 + ((dy_max - dy_min + 1) >> 1) + 1;
+        K.PW = TW / 2 + ((dx_max - dx_min + 1) >> 1) + 1;
+    } else {
+        K.PH = (TH - 1) * d->stride + (dy_max - dy_min) + 1;
+        K.PW = (TW - 1) * d->stride + (dx_max - dx_min) + 1;
+    }
+    K.plane = K.PH * K.PW;
+    DCVIC_CHECK_ARG(K.plane <= MAXSLOT * NTHREADS, "conv2d: patch %dx%d exceeds staging slots", K.PH, K.PW);
+    K.n_chunks = n_chunks_of(d);
+    K.n_cotiles = n_cotiles_of(d);
+    // taps per weight stage: keep the slab <= 40 KiB
+    int TG = (40 * 1024) / (KC * TC * 4);
+    if (TG < 1) TG = 1;
+    if (TG > d->T) TG = d->T;
+    K.TG = TG;
+    const size_t lds = (size_t)(((KC * K.plane + 3) & ~3) + TG * KC * TC) * sizeof(float);
+    DCVIC_CHECK_ARG(lds <= 160 * 1024, "conv2d: LDS %zu too large", lds);
+    const long long blocks = (long long)io->N * K.tiles_y * K.tiles_x * K.n_cotiles;
+    DCVIC_CHECK_ARG(blocks < (1ll << 31), "conv2d: grid too large");
+    hipStream_t st = (hipStream_t)stream;
+    switch (cfg) {
+        case 0: return launch_cfg<2, 4, 2, 2>(K, (int)blocks, lds, st);
+        case 1: return launch_cfg<2, 2, 1, 4>(K, (int)blocks, lds, st);
+        case 2: return launch_cfg<1, 2, 1, 4>(K, (int)blocks, lds, st);
+        default: return launch_cfg<3, 2, 1, 4>(K, (int)blocks, lds, st);
+    }
+}

@@ -1,0 +1,92 @@
+// gemm.hip -- batched strided GEMM on the fp32 MFMA (attention score / value products of the ldm
+// AttnBlock, model.py:186-196).  C[b][m][n] = alpha * sum_k A[b][m][k] * B[b][k][n], k ascending
+// (one fmaf per term), so results do not depend on the grid or the batch size.
+// 128x128 output tile per workgroup, 4 waves as 2x2, each wave 2x2 MFMA 32x32x2 tiles; operands are
+// staged through LDS as [k][m] / [k][n] images (+1 word of row padding) from arbitrary element strides.
+#include "common.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#define GK 16
+#define GT 128
+#define GTP (GT + 1)
+
+__global__ __launch_bounds__(256, 2) void bgemm_kernel(const dcvic_gemm_args g) {
+    __shared__ float As[GK * GTP];
+    __shared__ float Bs[GK * GTP];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int lane_k = lane >> 5, lane_j = lane & 31;
+    const int tiles_n = (g.N + GT - 1) / GT;
+    const int bt = blockIdx.x;
+    const int tn = bt % tiles_n, tm = bt / tiles_n;
+    const int b = blockIdx.y;
+    const int m0 = tm * GT, n0 = tn * GT;
+    const float* A = g.A + (long long)b * g.a_bs;
+    const float* B = g.B + (long long)b * g.b_bs;
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const bool a_kfast = (g.a_ks == 1);   // k contiguous in memory -> walk k fastest for coalescing
+    const bool b_kfast = (g.b_ks == 1);
+    for (int k0 = 0; k0 < g.K; k0 += GK) {
+        for (int e = tid; e < GK * GT; e += 256) {
+            int kk, mm;
+            if (a_kfast) { kk = e % GK; mm = e / GK; } else { mm = e % GT; kk = e / GT; }
+            float v = 0.f;
+            if (m0 + mm < g.M && k0 + kk < g.K) v = A[(long long)(m0 + mm) * g.a_ms + (long long)(k0 + kk) * g.a_ks];
+            As[kk * GTP + mm] = v;
+        }
+        for (int e = tid; e < GK * GT; e += 256) {
+            int kk, nn;
+            if (b_kfast) { kk = e % GK; nn = e / GK; } else { nn = e % GT; kk = e / GT; }
+            float v = 0.f;
+            if (n0 + nn < g.N && k0 + kk < g.K) v = B[(long long)(k0 + kk) * g.b_ks + (long long)(n0 + nn) * g.b_ns];
+            Bs[kk * GTP + nn] = v;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int ks = 0; ks < GK / 2; ++ks) {
+            float a[2], bb[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) a[i] = As[(2 * ks + lane_k) * GTP + wm * 64 + i * 32 + lane_j];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) bb[j] = Bs[(2 * ks + lane_k) * GTP + wn * 64 + j * 32 + lane_j];
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], bb[j], acc[i][j], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+    float* C = g.C + (long long)b * g.c_bs;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int nn = n0 + wn * 64 + j * 32 + lane_j;
+            if (nn >= g.N) continue;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int mm = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lane_k;
+                if (mm < g.M) C[(long long)mm * g.c_ms + nn] = g.alpha * acc[i][j][r];
+            }
+        }
+}
+
+extern "C" int dcvic_bgemm_f32(const dcvic_gemm_args* a, void* stream) {
+    DCVIC_CHECK_ARG(a && a->A && a->B && a->C, "bgemm: null pointer");
+    DCVIC_CHECK_ARG(a->batch > 0 && a->M > 0 && a->N > 0 && a->K > 0, "bgemm: bad sizes");
+    DCVIC_CHECK_ARG(a->batch <= 65535, "bgemm: batch too large");
+    const int tiles = dcvic_cdiv(a->M, GT) * dcvic_cdiv(a->N, GT);
+    dim3 grid(tiles, a->batch);
+    bgemm_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(*a);
+    DCVIC_CHECK_LAUNCH("bgemm");
+    return DCVIC_OK;
+}

@@ -1,0 +1,160 @@
+// rate.hip -- rate estimation + symbolisation of the learned entropy model.
+//
+// dcvic_gaussian_rate_f32: GaussianConditional (CompressAI 1.2.4) as driven by
+//   ste_gaussian_conditional.py:16-23 and minnen20_charm_context_model.py:96,148,164,199:
+//     sym = rint(y - mu); y_hat = sym + mu; v = |y_hat - mu|; s = max(sigma, 0.11)
+//     p = max(0.5 erfc(-(0.5 - v)/(s sqrt2)) - 0.5 erfc(-(-0.5 - v)/(s sqrt2)), 1e-9)
+//     index = (n_scales - 1) - #{t in table[:-1] : s <= t}
+//   decode mode (y == NULL): y_hat = float(sym_in) + mu.
+// dcvic_eb_rate_f32: EntropyBottleneck eval forward (entropy_bottleneck.py:19-28 -> App-B).
+// Both are 12-20 B/element streaming kernels.  One workgroup owns one image, walks it in a fixed
+// order and reduces -log2 p with a fixed tree in fp64, so bits[n] is deterministic and independent
+// of the batch size; bits_out[n] is ACCUMULATED (+=) so CHARM slices can add up.
+#include "common.h"
+
+__device__ __forceinline__ double block_sum_d(double v, double* red) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    __syncthreads();
+    if (lane == 0) red[w] = v;
+    __syncthreads();
+    double t = 0.0;
+    for (int i = 0; i < nw; ++i) t += red[i];
+    return t;
+}
+
+__device__ __forceinline__ float std_cumulative(float x) { return 0.5f * erfcf(-0.70710678118654752440f * x); }
+
+__global__ __launch_bounds__(256) void gaussian_rate_kernel(const float* __restrict__ y, long long y_bs,
+                                                            const int32_t* __restrict__ sym_in, const float* __restrict__ mu,
+                                                            const float* __restrict__ sigma, long long ms_bs,
+                                                            const float* __restrict__ table, int n_scales,
+                                                            float* __restrict__ y_hat, long long yh_bs,
+                                                            int32_t* __restrict__ sym_out, int32_t* __restrict__ index_out,
+                                                            long long si_bs, float* __restrict__ lik_out,
+                                                            float* __restrict__ bits_out, long long CHW) {
+    __shared__ double red[4];
+    __shared__ float tab[64];
+    const int n = blockIdx.x;
+    for (int i = threadIdx.x; i < n_scales && i < 64; i += blockDim.x) tab[i] = table[i];
+    __syncthreads();
+    double acc = 0.0;
+    for (long long i = threadIdx.x; i < CHW; i += blockDim.x) {
+        const float m = mu[n * ms_bs + i];
+        const float s = fmaxf(sigma[n * ms_bs + i], 0.11f);
+        float sym;
+        if (y) sym = rintf(__fsub_rn(y[n * y_bs + i], m));
+        else sym = (float)sym_in[n * si_bs + i];
+        const float yh = __fadd_rn(sym, m);
+        if (y_hat) y_hat[n * yh_bs + i] = yh;
+        if (sym_out) sym_out[n * si_bs + i] = (int32_t)sym;
+        if (index_out) {
+            int ix = n_scales - 1;
+            for (int t = 0; t < n_scales - 1; ++t) ix -= (s <= tab[t]) ? 1 : 0;
+            index_out[n * si_bs + i] = ix;
+        }
+        if (lik_out || bits_out) {
+            const float v = fabsf(__fsub_rn(yh, m));
+            const float up = std_cumulative((0.5f - v) / s);
+            const float lo = std_cumulative((-0.5f - v) / s);
+            const float p = fmaxf(up - lo, 1e-9f);
+            if (lik_out) lik_out[n * si_bs + i] = p;
+            acc += (double)logf(p);
+        }
+    }
+    if (bits_out) {
+        const double t = block_sum_d(acc, red);
+        if (threadIdx.x == 0) bits_out[n] += (float)(-t / 0.693147180559945309417);
+    }
+}
+
+extern "C" int dcvic_gaussian_rate_f32(const float* y, long long y_bs, const int32_t* sym_in, const float* mu,
+                                       const float* sigma, long long ms_bs, const float* scale_table, int n_scales,
+                                       float* y_hat, long long yh_bs, int32_t* sym_out, int32_t* index_out, long long si_bs,
+                                       float* lik_out, float* bits_out, int N, int C, int HW, void* stream) {
+    DCVIC_CHECK_ARG(mu && sigma && scale_table && N > 0 && C > 0 && HW > 0, "gaussian_rate: bad argument");
+    DCVIC_CHECK_ARG((y != nullptr) != (sym_in != nullptr), "gaussian_rate: exactly one of y / sym_in must be given");
+    DCVIC_CHECK_ARG(n_scales >= 2 && n_scales <= 64, "gaussian_rate: n_scales %d", n_scales);
+    const long long CHW = (long long)C * HW;
+    DCVIC_CHECK_ARG(ms_bs >= CHW && si_bs >= CHW, "gaussian_rate: batch stride too small");
+    gaussian_rate_kernel<<<N, 256, 0, (hipStream_t)stream>>>(y, y_bs, sym_in, mu, sigma, ms_bs, scale_table, n_scales, y_hat,
+                                                           yh_bs, sym_out, index_out, si_bs, lik_out, bits_out, CHW);
+    DCVIC_CHECK_LAUNCH("gaussian_rate");
+    return DCVIC_OK;
+}
+
+// Per-channel parameter pack (host side precomputes softplus(matrix) and tanh(factor)):
+//   matrices [C][33]: m0 (3x1), m1..m3 (3x3 row-major), m4 (1x3);  biases [C][13]: b0..b3 (3), b4 (1);
+//   factors  [C][12]: f0..f3 (3).
+__device__ __forceinline__ float eb_logits(float x, const float* M, const float* Bv, const float* Fv) {
+    float v[3], u[3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) { v[r] = M[r] * x + Bv[r]; v[r] += Fv[r] * tanhf(v[r]); }
+#pragma unroll
+    for (int l = 1; l < 4; ++l) {
+        const float* m = M + 3 + (l - 1) * 9;
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            float a = m[r * 3 + 0] * v[0];
+            a += m[r * 3 + 1] * v[1];
+            a += m[r * 3 + 2] * v[2];
+            a += Bv[l * 3 + r];
+            u[r] = a + Fv[l * 3 + r] * tanhf(a);
+        }
+#pragma unroll
+        for (int r = 0; r < 3; ++r) v[r] = u[r];
+    }
+    const float* m4 = M + 30;
+    float a = m4[0] * v[0];
+    a += m4[1] * v[1];
+    a += m4[2] * v[2];
+    return a + Bv[12];
+}
+
+__global__ __launch_bounds__(256) void eb_rate_kernel(const float* __restrict__ z, const int32_t* __restrict__ sym_in,
+                                                      const float* __restrict__ matrices,
+                                                      const float* __restrict__ biases, const float* __restrict__ factors,
+                                                      const float* __restrict__ medians, float* __restrict__ z_hat,
+                                                      int32_t* __restrict__ sym_out, float* __restrict__ lik_out,
+                                                      float* __restrict__ bits_out, int C, int HW) {
+    __shared__ double red[4];
+    const int n = blockIdx.x;
+    const long long CHW = (long long)C * HW;
+    double acc = 0.0;
+    for (long long i = threadIdx.x; i < CHW; i += blockDim.x) {
+        const int c = (int)(i / HW);
+        const float med = medians[c];
+        const float sym = z ? rintf(__fsub_rn(z[n * CHW + i], med)) : (float)sym_in[n * CHW + i];
+        const float zh = __fadd_rn(sym, med);
+        if (z_hat) z_hat[n * CHW + i] = zh;
+        if (sym_out) sym_out[n * CHW + i] = (int32_t)sym;
+        if (lik_out || bits_out) {
+            const float* M = matrices + c * 33;
+            const float* Bv = biases + c * 13;
+            const float* Fv = factors + c * 12;
+            const float lower = eb_logits(zh - 0.5f, M, Bv, Fv);
+            const float upper = eb_logits(zh + 0.5f, M, Bv, Fv);
+            const float t = lower + upper;
+            const float sg = t > 0.f ? -1.f : (t < 0.f ? 1.f : 0.f);
+            const float a = 1.f / (1.f + expf(-sg * upper)), b = 1.f / (1.f + expf(-sg * lower));
+            const float p = fmaxf(fabsf(a - b), 1e-9f);
+            if (lik_out) lik_out[n * CHW + i] = p;
+            acc += (double)logf(p);
+        }
+    }
+    if (bits_out) {
+        const double t = block_sum_d(acc, red);
+        if (threadIdx.x == 0) bits_out[n] += (float)(-t / 0.693147180559945309417);
+    }
+}
+
+extern "C" int dcvic_eb_rate_f32(const float* z, const int32_t* sym_in, const float* matrices, const float* biases,
+                                 const float* factors, const float* medians, float* z_hat, int32_t* sym_out, float* lik_out,
+                                 float* bits_out, int N, int C, int HW, void* stream) {
+    DCVIC_CHECK_ARG(matrices && biases && factors && medians && N > 0 && C > 0 && HW > 0, "eb_rate: bad argument");
+    DCVIC_CHECK_ARG((z != nullptr) != (sym_in != nullptr), "eb_rate: exactly one of z / sym_in must be given");
+    eb_rate_kernel<<<N, 256, 0, (hipStream_t)stream>>>(z, sym_in, matrices, biases, factors, medians, z_hat, sym_out, lik_out, bits_out, C, HW);
+    DCVIC_CHECK_LAUNCH("eb_rate");
+    return DCVIC_OK;
+}

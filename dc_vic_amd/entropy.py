@@ -1,0 +1,295 @@
+"""Entropy models of the DC-VIC path, MI355X-native.
+
+Mirror of the reference's wrappers
+  src/models/subnet/entropy_model/entropy_bottleneck.py:13-28   (EntropyBottleneck / SteEntropyBottleneck)
+  src/models/subnet/entropy_model/gaussian_conditional.py:17-24 (GaussianMeanScaleConditional)
+  src/models/subnet/entropy_model/ste_gaussian_conditional.py:9-23
+which subclass CompressAI 1.2.4 classes (not vendored by the reference).  Here they are
+self-contained: likelihoods / symbols / CDF indexes run as HIP kernels (csrc/rate.hip), CDF tables
+are built once on the host at `update()` time (the reference's codec_setup, hyperprior_dc_vic_model.py:
+65-68) and the rANS coder is the C++ host coder in csrc/host_entropy.cpp.  Inference only (the
+training-time noise / STE branches raise).
+
+Parameter and buffer names follow CompressAI 1.2.4 so reference checkpoints load
+(SURVEY App-B / App-E): `_matrix{i}`, `_bias{i}`, `_factor{i}`, `quantiles`, `_offset`,
+`_quantized_cdf`, `_cdf_length`, `scale_table`.
+"""
+from __future__ import annotations
+
+import math
+import os
+from typing import Dict, List, Optional, Tuple
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import ops
+from .registry import ENTROPYMODEL_REGISTRY
+
+Tensor = torch.Tensor
+
+SCALES_MIN, SCALES_MAX, SCALES_LEVELS = 0.11, 256.0, 64
+TAIL_MASS = 1e-9
+
+
+def get_scale_table(min_: float = SCALES_MIN, max_: float = SCALES_MAX, levels: int = SCALES_LEVELS) -> Tensor:
+    """compressai.models.get_scale_table (imported at hyperprior_dc_vic_model.py:10)."""
+    return torch.exp(torch.linspace(math.log(min_), math.log(max_), levels))
+
+
+def host_threads() -> int:
+    env = os.environ.get("DCVIC_HOST_THREADS")
+    if env:
+        return max(1, int(env))
+    return max(1, min(16, (os.cpu_count() or 1)))
+
+
+def _pmf_to_cdf(pmf: Tensor, tail_mass: Tensor, pmf_length: Tensor, max_length: int) -> np.ndarray:
+    cdf = np.zeros((len(pmf_length), max_length + 2), dtype=np.int32)
+    for i in range(len(pmf_length)):
+        prob = torch.cat((pmf[i, : int(pmf_length[i])], tail_mass[i].reshape(-1)), dim=0).numpy()
+        c = ops.pmf_to_quantized_cdf(prob)
+        cdf[i, : c.size] = c
+    return cdf
+
+
+def pack_entropy_bottleneck(sd: Dict[str, Tensor], prefix: str):
+    """Per-channel parameter pack for csrc/rate.hip: softplus(matrix), bias, tanh(factor), medians."""
+    g = lambda k: sd[f"{prefix}.{k}"].detach().float()
+    C = g("quantiles").shape[0]
+    mats = torch.cat([torch.nn.functional.softplus(g(f"_matrix{i}")).reshape(C, -1) for i in range(5)], dim=1).contiguous()
+    biases = torch.cat([g(f"_bias{i}").reshape(C, -1) for i in range(5)], dim=1).contiguous()
+    factors = torch.cat([torch.tanh(g(f"_factor{i}")).reshape(C, -1) for i in range(4)], dim=1).contiguous()
+    med = g("quantiles")[:, 0, 1].contiguous()
+    assert mats.shape[1] == 33 and biases.shape[1] == 13 and factors.shape[1] == 12
+    return mats, biases, factors, med
+
+
+class _TableOwner(nn.Module):
+    """Shared CDF-table plumbing (EntropyModel in CompressAI)."""
+
+    def __init__(self):
+        super().__init__()
+        self.register_buffer("_offset", torch.IntTensor())
+        self.register_buffer("_quantized_cdf", torch.IntTensor())
+        self.register_buffer("_cdf_length", torch.IntTensor())
+        self._tables: Optional[ops.CdfTables] = None
+
+    def _load_from_state_dict(self, state_dict, prefix, *args, **kwargs):
+        # compressai.models.utils.update_registered_buffers (base_model.py:88-104): resize the
+        # initially empty buffers to the checkpoint's shapes before the copy
+        for name in ("_offset", "_quantized_cdf", "_cdf_length", "scale_table"):
+            key = prefix + name
+            if key in state_dict and hasattr(self, name):
+                cur = getattr(self, name)
+                if cur.shape != state_dict[key].shape:
+                    setattr(self, name, torch.empty_like(state_dict[key], device=cur.device))
+        self._tables = None
+        return super()._load_from_state_dict(state_dict, prefix, *args, **kwargs)
+
+    def _set_tables(self, cdf: np.ndarray, lengths: np.ndarray, offsets: np.ndarray):
+        dev = self._offset.device
+        self._quantized_cdf = torch.from_numpy(cdf).to(dev)
+        self._cdf_length = torch.from_numpy(np.ascontiguousarray(lengths, dtype=np.int32)).to(dev)
+        self._offset = torch.from_numpy(np.ascontiguousarray(offsets, dtype=np.int32)).to(dev)
+        self._tables = ops.CdfTables(cdf, lengths, offsets)
+
+    def tables(self) -> ops.CdfTables:
+        if self._tables is None:
+            if self._quantized_cdf.numel() == 0:
+                raise RuntimeError("entropy model tables are empty: call update() / codec_setup() first")
+            self._tables = ops.CdfTables(self._quantized_cdf.cpu().numpy(), self._cdf_length.cpu().numpy(), self._offset.cpu().numpy())
+        return self._tables
+
+
+@ENTROPYMODEL_REGISTRY.register()
+class EntropyBottleneck(_TableOwner):
+    """Fully factorised prior on z (CompressAI EntropyBottleneck, filters (3,3,3,3))."""
+
+    def __init__(self, channels: int, tail_mass: float = 1e-9, init_scale: float = 10, filters=(3, 3, 3, 3)):
+        super().__init__()
+        self.channels = int(channels)
+        self.filters = tuple(int(f) for f in filters)
+        assert self.filters == (3, 3, 3, 3), "the HIP kernel is written for filters (3,3,3,3)"
+        self.init_scale = float(init_scale)
+        self.tail_mass = float(tail_mass)
+        f = (1,) + self.filters + (1,)
+        scale = self.init_scale ** (1 / (len(self.filters) + 1))
+        for i in range(len(self.filters) + 1):
+            init = np.log(np.expm1(1 / scale / f[i + 1]))
+            m = torch.full((channels, f[i + 1], f[i]), float(init))
+            self.register_parameter(f"_matrix{i}", nn.Parameter(m))
+            b = torch.empty(channels, f[i + 1], 1).uniform_(-0.5, 0.5)
+            self.register_parameter(f"_bias{i}", nn.Parameter(b))
+            if i < len(self.filters):
+                self.register_parameter(f"_factor{i}", nn.Parameter(torch.zeros(channels, f[i + 1], 1)))
+        q = torch.Tensor([-self.init_scale, 0, self.init_scale]).repeat(channels, 1, 1)
+        self.quantiles = nn.Parameter(q)
+        target = np.log(2 / self.tail_mass - 1)
+        self.register_buffer("target", torch.Tensor([-target, 0, target]))
+        self._packs = None
+        self._packs_key = None
+
+    def _get_medians(self) -> Tensor:
+        return self.quantiles[:, :, 1:2]
+
+    def packs(self):
+        key = tuple((p.data_ptr(), p._version) for p in self.parameters())
+        if self._packs is None or self._packs_key != key:
+            sd = {f"eb.{k}": v for k, v in self.state_dict().items()}
+            self._packs = pack_entropy_bottleneck(sd, "eb")
+            self._packs_key = key
+        return self._packs
+
+    # -- eval forward (entropy_bottleneck.py:13-16 -> CompressAI forward(training=False))
+    def forward(self, x: Tensor, is_train: bool = False, bits_out: Optional[Tensor] = None) -> Tuple[Tensor, Tensor]:
+        if is_train:
+            raise NotImplementedError("dc_vic_amd implements the inference path only")
+        x = x.contiguous()
+        x_hat = torch.empty_like(x)
+        lik = torch.empty_like(x)
+        ops.eb_rate(x, self.packs(), x_hat, None, lik, bits_out)
+        return x_hat, lik
+
+    def symbols(self, x: Tensor) -> Tuple[Tensor, Tensor]:
+        x = x.contiguous()
+        x_hat = torch.empty_like(x)
+        sym = torch.empty(x.shape, dtype=torch.int32, device=x.device)
+        ops.eb_rate(x, self.packs(), x_hat, sym, None, None)
+        return sym, x_hat
+
+    def _logits_cumulative_host(self, v: Tensor) -> Tensor:
+        p = {k: t.detach().cpu().float() for k, t in self.named_parameters()}
+        logits = v
+        for i in range(5):
+            logits = torch.matmul(torch.nn.functional.softplus(p[f"_matrix{i}"]), logits) + p[f"_bias{i}"]
+            if i < 4:
+                logits = logits + torch.tanh(p[f"_factor{i}"]) * torch.tanh(logits)
+        return logits
+
+    def update(self, force: bool = False) -> bool:
+        """Build the per-channel integer CDFs (host, once per model)."""
+        if self._offset.numel() > 0 and not force:
+            return False
+        q = self.quantiles.detach().cpu().float()
+        med = q[:, 0, 1]
+        minima = torch.clamp(torch.ceil(med - q[:, 0, 0]).int(), min=0)
+        maxima = torch.clamp(torch.ceil(q[:, 0, 2] - med).int(), min=0)
+        pmf_start = med - minima
+        pmf_length = maxima + minima + 1
+        max_length = int(pmf_length.max())
+        samples = torch.arange(max_length)[None, :] + pmf_start[:, None, None]
+        lower = self._logits_cumulative_host(samples - 0.5)
+        upper = self._logits_cumulative_host(samples + 0.5)
+        sign = -torch.sign(lower + upper)
+        pmf = torch.abs(torch.sigmoid(sign * upper) - torch.sigmoid(sign * lower))[:, 0, :]
+        tail = torch.sigmoid(lower[:, 0, :1]) + torch.sigmoid(-upper[:, 0, -1:])
+        cdf = _pmf_to_cdf(pmf, tail, pmf_length, max_length)
+        self._set_tables(cdf, (pmf_length + 2).numpy(), (-minima).numpy())
+        return True
+
+    def _channel_indexes(self, n: int, hw: int) -> np.ndarray:
+        return np.broadcast_to(np.repeat(np.arange(self.channels, dtype=np.int32), hw)[None, :], (n, self.channels * hw))
+
+    def compress(self, x: Tensor) -> List[bytes]:
+        """EntropyBottleneck.compress: one rANS stream per batch item."""
+        sym, _ = self.symbols(x)
+        N, C, H, W = x.shape
+        s = sym.reshape(N, -1).cpu().numpy()
+        return self.tables().encode(s, self._channel_indexes(N, H * W), threads=host_threads())
+
+    def decompress(self, strings: List[bytes], size: Tuple[int, int]) -> Tensor:
+        """Returns de-quantised values (medians added), like CompressAI."""
+        H, W = size
+        N = len(strings)
+        dec = self.tables().decoders(strings)
+        sym = dec.decode(self._channel_indexes(N, H * W), threads=host_threads())
+        dec.close()
+        dev = self.quantiles.device
+        s_dev = torch.from_numpy(sym).to(dev).view(N, self.channels, H, W).contiguous()
+        z_hat = torch.empty((N, self.channels, H, W), dtype=torch.float32, device=dev)
+        ops.eb_rate(None, self.packs(), z_hat, None, None, None, sym_in=s_dev)
+        return z_hat
+
+    @staticmethod
+    def dequantize(inputs: Tensor, means: Optional[Tensor] = None, dtype=torch.float) -> Tensor:
+        if means is not None:
+            return inputs.type_as(means) + means
+        return inputs.type(dtype)
+
+
+@ENTROPYMODEL_REGISTRY.register()
+class SteEntropyBottleneck(EntropyBottleneck):
+    """entropy_bottleneck.py:19-28; identical to the parent in eval mode."""
+
+
+@ENTROPYMODEL_REGISTRY.register()
+class GaussianMeanScaleConditional(_TableOwner):
+    """gaussian_conditional.py:17-24 over CompressAI GaussianConditional(scale_table=None, scale_bound)."""
+
+    def __init__(self, scale_bound: Optional[float] = None, tail_mass: float = 1e-9, **kwargs):
+        super().__init__()
+        self.scale_bound = 0.11 if scale_bound is None else float(scale_bound)
+        if abs(self.scale_bound - 0.11) > 1e-12:
+            raise NotImplementedError("the HIP rate kernel hard-codes scale_bound 0.11 (yaml:58)")
+        self.tail_mass = float(tail_mass)
+        self.register_buffer("scale_table", torch.Tensor())
+
+    def update_scale_table(self, scale_table: Tensor, force: bool = False) -> bool:
+        if self._offset.numel() > 0 and not force:
+            return False
+        self.scale_table = torch.as_tensor(scale_table, dtype=torch.float32).to(self._offset.device)
+        self.update()
+        return True
+
+    def update(self):
+        from scipy.stats import norm
+        table = self.scale_table.detach().cpu().float()
+        multiplier = -norm.ppf(self.tail_mass / 2)
+        pmf_center = torch.ceil(table * multiplier).int()
+        pmf_length = 2 * pmf_center + 1
+        max_length = int(pmf_length.max())
+        samples = torch.abs(torch.arange(max_length).int() - pmf_center[:, None]).float()
+        sc = table.unsqueeze(1)
+        cum = lambda t: 0.5 * torch.erfc(float(-(2 ** -0.5)) * t)
+        upper = cum((0.5 - samples) / sc)
+        lower = cum((-0.5 - samples) / sc)
+        pmf = upper - lower
+        tail = 2 * lower[:, :1]
+        cdf = _pmf_to_cdf(pmf, tail, pmf_length, max_length)
+        self._set_tables(cdf, (pmf_length + 2).numpy(), (-pmf_center).numpy())
+
+    def _table_dev(self, like: Tensor) -> Tensor:
+        if self.scale_table.numel() == 0:
+            self.scale_table = get_scale_table().to(like.device)
+        return self.scale_table
+
+    # forward(y, params, is_train) -> (y_hat, likelihood)      ste_gaussian_conditional.py:16-23
+    def forward(self, y: Tensor, params: Tensor, is_train: bool = False, bits_out: Optional[Tensor] = None):
+        if is_train:
+            raise NotImplementedError("dc_vic_amd implements the inference path only")
+        mean, std = params.chunk(2, 1)
+        y_hat = torch.empty(y.shape, dtype=torch.float32, device=y.device)
+        lik = torch.empty(y.shape, dtype=torch.float32, device=y.device)
+        ops.gaussian_rate(y, None, mean, std, self._table_dev(y), y_hat, None, None, lik, bits_out)
+        return y_hat, lik
+
+    def build_indexes(self, scales: Tensor) -> Tensor:
+        idx = torch.empty(scales.shape, dtype=torch.int32, device=scales.device)
+        ops.gaussian_rate(None, torch.zeros_like(idx), scales, scales, self._table_dev(scales), None, None, idx, None, None)
+        return idx
+
+    @staticmethod
+    def dequantize(inputs: Tensor, means: Optional[Tensor] = None, dtype=torch.float) -> Tensor:
+        if means is not None:
+            return inputs.type_as(means) + means
+        return inputs.type(dtype)
+
+
+@ENTROPYMODEL_REGISTRY.register()
+class SteGaussianMeanScaleConditional(GaussianMeanScaleConditional):
+    def __init__(self, scale_bound=None, entropy_quant_type="noise", **kwargs):
+        super().__init__(scale_bound=scale_bound)
+        assert entropy_quant_type == "noise"
+        self.entropy_quant_type = entropy_quant_type

@@ -159,3 +159,16 @@ def full_synth_state_dict(seed: int = 1234) -> Dict[str, torch.Tensor]:
     sd = synth_state_dict(man, seed)
     sd.update(_eb_params(192, seed, "entropy_model_z"))
     return sd
+
+
+def load_synth_weights(model, seed: int = 1234) -> Dict[str, torch.Tensor]:
+    """Load the deterministic synthetic weights into a dc_vic_amd comp model (in place) and return
+    the CPU state dict that was loaded (the oracle consumes the same dict)."""
+    sd = full_synth_state_dict(seed)
+    own = model.state_dict()
+    missing = [k for k in sd if k not in own]
+    if missing:
+        raise KeyError(f"synthetic weights name parameters the model lacks: {missing[:5]}")
+    merged = {k: (sd[k] if k in sd else v) for k, v in own.items()}
+    model.load_state_dict(merged)
+    return sd

@@ -1,0 +1,39 @@
+"""The C-ABI library loads and exports every symbol include/dcvic.h declares (no compute calls: CPU box)."""
+import os
+import re
+
+from dc_vic_amd import _lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    txt = open(os.path.join(ROOT, "include", "dcvic.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(dcvic_[a-zA-Z0-9_]+)\s*\(", txt)))
+
+
+def test_library_exports_every_declared_symbol():
+    L = _lib.lib()
+    names = declared_symbols()
+    assert len(names) >= 28
+    for n in names:
+        assert hasattr(L, n), f"{n} declared in include/dcvic.h but not exported"
+    assert sorted(_lib.SYMBOLS) == names
+
+
+def test_error_reporting_without_gpu():
+    L = _lib.lib()
+    assert L.dcvic_version() >= 100
+    # argument validation happens before any HIP call
+    rc = L.dcvic_pmf_to_quantized_cdf_host(None, 0, None)
+    assert rc == -1 and b"pmf_to_quantized_cdf" in L.dcvic_last_error()
+    d = _lib.ConvDesc()
+    import ctypes as C
+    assert L.dcvic_conv_desc_init(C.byref(d), 8, 8, 7, 7, 1, 0, 0, 0) == -1     # 49 taps > 25
+    assert L.dcvic_conv_desc_init(C.byref(d), 128, 128, 3, 3, 1, 1, 1, 0) == 0
+    assert d.T == 9 and d.tap_dy[0] == -1 and d.tap_dx[8] == 1
+    assert L.dcvic_conv_packed_bytes(C.byref(d)) == 128 * 128 * 9 * 4
+    assert L.dcvic_convT_phase_desc(C.byref(d), 192, 192, 5, 0, 0) == 0 and d.T == 9
+    assert L.dcvic_convT_phase_desc(C.byref(d), 192, 192, 5, 1, 1) == 0 and d.T == 4
+    assert L.dcvic_convT_phase_desc(C.byref(d), 192, 192, 5, 0, 1) == 0 and d.T == 6

@@ -1,0 +1,330 @@
+"""Kernel-level parity on a real MI355X: every C-ABI compute entry point against the same operator
+evaluated on the CPU (torch fp32 functional ops / the oracle's entropy formulas).  Tolerances are
+written per test; integer outputs (indices, symbols, cdf indexes, bytes) are compared exactly."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need a HIP device"
+    from dc_vic_amd import _lib
+    _lib.lib()
+    return torch.device("cuda:0")
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(*shape, generator=g) * scale
+
+
+def close(a, b, rtol=1e-4, atol=1e-4):
+    a = a.detach().cpu().double().numpy()
+    b = b.detach().cpu().double().numpy()
+    np.testing.assert_allclose(a, b, rtol=rtol, atol=atol)
+
+
+CONV_CASES = [
+    # Cin, Cout, k, stride, pad, H, W, N
+    (128, 128, 3, 1, 1, 40, 72, 2),     # cfg 0 (TC 128), ragged tiles
+    (8, 256, 3, 1, 1, 16, 16, 1),       # two cout tiles
+    (3, 192, 5, 2, 2, 64, 48, 2),       # ELIC conv1: Cin 3 (channel padding), cfg 3, 5x5 s2
+    (192, 96, 1, 1, 0, 32, 32, 1),      # bottleneck 1x1, cfg 3
+    (96, 96, 3, 1, 1, 17, 9, 3),        # odd sizes
+    (192, 320, 3, 1, 1, 16, 16, 1),     # hyper encoder conv1 (3 cout tiles of 128)
+    (320, 256, 5, 2, 2, 16, 16, 2),     # hyper encoder conv2
+    (256, 192, 5, 2, 2, 8, 8, 2),       # -> 4x4 (tiny map, TW 4)
+    (160, 224, 5, 1, 2, 16, 16, 2),     # CHARM 5x5 s1, tap groups, cfg 0 with Cout 224
+    (128, 32, 3, 1, 1, 16, 16, 2),      # CHARM out, cfg 2
+    (512, 4, 3, 1, 1, 32, 32, 1),       # conv_out -> 4 channels
+    (4, 512, 3, 1, 1, 32, 32, 1),       # decoder conv_in: Cin 4
+    (128, 3, 3, 1, 1, 64, 64, 1),       # final conv -> 3
+    (64, 64, 3, 1, 1, 5, 3, 1),         # smaller than any tile
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv2d(dev, case):
+    from dc_vic_amd import ops
+    Cin, Cout, k, stride, pad, H, W, N = case
+    x = rnd(N, Cin, H, W, seed=1)
+    w = rnd(Cout, Cin, k, k, seed=2, scale=(Cin * k * k) ** -0.5)
+    b = rnd(Cout, seed=3, scale=0.1)
+    ref = F.conv2d(x, w, b, stride=stride, padding=pad)
+    plan = ops.ConvPlan(w.to(dev), b.to(dev), "conv", stride=stride, pad=(pad, pad))
+    out = plan(x.to(dev))
+    assert out.shape == ref.shape
+    close(out, ref, rtol=2e-4, atol=2e-5)
+
+
+def test_conv_epilogue_and_sources(dev):
+    """bias -> act -> +res -> beta-FT affine; three concatenated sources with odd channel splits;
+    output written into a channel slice of a larger buffer."""
+    from dc_vic_amd import ops
+    N, H, W = 2, 24, 40
+    a, b_, c = rnd(N, 260, H, W, seed=4), rnd(N, 100, H, W, seed=5), rnd(N, 92, H, W, seed=6)
+    w = rnd(192, 452, 3, 3, seed=7, scale=(452 * 9) ** -0.5)
+    bias = rnd(192, seed=8, scale=0.1)
+    res = rnd(N, 192, H, W, seed=9)
+    sc, sh = rnd(N, 192, seed=10, scale=0.3), rnd(N, 192, seed=11, scale=0.3)
+    ref = F.relu(F.conv2d(torch.cat([a, b_, c], 1), w, bias, padding=1)) + res
+    ref = ref * (1 + sc[:, :, None, None]) + sh[:, :, None, None]
+    big = torch.zeros(N, 300, H, W, device=dev)
+    # sources as channel slices of bigger buffers (non-trivial batch strides)
+    abuf = torch.zeros(N, 300, H, W, device=dev); abuf[:, 20:280] = a.to(dev)
+    plan = ops.ConvPlan(w.to(dev), bias.to(dev), "conv", pad=(1, 1))
+    plan([abuf[:, 20:280], b_.to(dev), c.to(dev)], out=big[:, 50:242], act=ops.ACT_RELU, res=res.to(dev),
+         affine=(sc.to(dev).contiguous(), sh.to(dev).contiguous()))
+    close(big[:, 50:242], ref, rtol=2e-4, atol=5e-5)
+    assert float(big[:, :50].abs().max()) == 0.0 and float(big[:, 242:].abs().max()) == 0.0
+    # shared (batch-1) affine vectors
+    out2 = plan([abuf[:, 20:280], b_.to(dev), c.to(dev)], act=ops.ACT_NONE, affine=(sc[:1].to(dev).contiguous(), sh[:1].to(dev).contiguous()))
+    ref2 = F.conv2d(torch.cat([a, b_, c], 1), w, bias, padding=1) * (1 + sc[:1, :, None, None]) + sh[:1, :, None, None]
+    close(out2, ref2, rtol=2e-4, atol=5e-5)
+
+
+@pytest.mark.parametrize("H,W", [(16, 16), (12, 20), (32, 64)])
+def test_conv_upsample_fused(dev, H, W):
+    """ldm Upsample: nearest x2 then conv3x3 (model.py:53-57), fused in the patch loader."""
+    from dc_vic_amd import ops
+    x = rnd(2, 64, H, W, seed=12)
+    w = rnd(64, 64, 3, 3, seed=13, scale=(64 * 9) ** -0.5)
+    b = rnd(64, seed=14, scale=0.1)
+    ref = F.conv2d(F.interpolate(x, scale_factor=2.0, mode="nearest"), w, b, padding=1)
+    out = ops.ConvPlan(w.to(dev), b.to(dev), "conv", pad=(1, 1), upsample=True)(x.to(dev))
+    close(out, ref, rtol=2e-4, atol=2e-5)
+
+
+@pytest.mark.parametrize("H,W", [(32, 32), (17, 33), (64, 40)])
+def test_conv_downsample_asym_pad(dev, H, W):
+    """ldm Downsample: F.pad (0,1,0,1) then conv3x3 stride 2 pad 0 (model.py:72-76)."""
+    from dc_vic_amd import ops
+    x = rnd(2, 128, H, W, seed=15)
+    w = rnd(128, 128, 3, 3, seed=16, scale=(128 * 9) ** -0.5)
+    b = rnd(128, seed=17, scale=0.1)
+    ref = F.conv2d(F.pad(x, (0, 1, 0, 1)), w, b, stride=2)
+    out = ops.ConvPlan(w.to(dev), b.to(dev), "conv", stride=2, pad=(0, 0))(x.to(dev), out_hw=tuple(ref.shape[2:]))
+    close(out, ref, rtol=2e-4, atol=2e-5)
+
+
+@pytest.mark.parametrize("Cin,Cout,k,H,W", [(192, 192, 5, 16, 16), (192, 256, 5, 4, 6), (256, 128, 3, 16, 24), (192, 192, 5, 9, 7)])
+def test_conv_transpose(dev, Cin, Cout, k, H, W):
+    """ConvTranspose2d(k5,s2,p2,op1) as four sub-pixel phases; (k3,s1,p1) as a flipped conv."""
+    from dc_vic_amd import ops
+    x = rnd(2, Cin, H, W, seed=18)
+    w = rnd(Cin, Cout, k, k, seed=19, scale=(Cin * k * k / 4) ** -0.5)
+    b = rnd(Cout, seed=20, scale=0.1)
+    if k == 5:
+        ref = F.conv_transpose2d(x, w, b, stride=2, padding=2, output_padding=1)
+    else:
+        ref = F.conv_transpose2d(x, w, b, stride=1, padding=1)
+    out = ops.ConvPlan(w.to(dev), b.to(dev), "convT")(x.to(dev), act=ops.ACT_NONE)
+    assert out.shape == ref.shape
+    close(out, ref, rtol=2e-4, atol=2e-5)
+
+
+def test_conv_batch_invariance(dev):
+    """Bit-identical results for an image alone and inside a batch (encoder/decoder agreement)."""
+    from dc_vic_amd import ops
+    x = rnd(5, 160, 16, 16, seed=21).to(dev)
+    w = rnd(224, 160, 5, 5, seed=22, scale=0.02).to(dev)
+    plan = ops.ConvPlan(w, None, "conv", pad=(2, 2))
+    full = plan(x)
+    for i in (0, 3, 4):
+        single = plan(x[i:i + 1].contiguous())
+        assert torch.equal(single[0], full[i])
+
+
+@pytest.mark.parametrize("C,H,W,act", [(128, 32, 32, 3), (704, 8, 12, 3), (256, 16, 16, 0), (96, 5, 7, 3)])
+def test_groupnorm(dev, C, H, W, act):
+    from dc_vic_amd import ops
+    if C % 32:
+        pytest.skip("32 groups")
+    x = rnd(2, C, H, W, seed=23, scale=2.0) + 0.5
+    g, b = 1 + 0.1 * rnd(C, seed=24), 0.1 * rnd(C, seed=25)
+    ref = F.group_norm(x, 32, g, b, eps=1e-6)
+    if act == 3:
+        ref = ref * torch.sigmoid(ref)
+    out = ops.groupnorm(x.to(dev), g.to(dev), b.to(dev), act=act)
+    close(out, ref, rtol=1e-4, atol=1e-5)
+    # channel-slice views in and out
+    big = torch.zeros(2, C + 64, H, W, device=dev); big[:, 32:32 + C] = x.to(dev)
+    o2 = torch.zeros(2, C + 10, H, W, device=dev)
+    ops.groupnorm(big[:, 32:32 + C], g.to(dev), b.to(dev), act=act, out=o2[:, 10:])
+    close(o2[:, 10:], ref, rtol=1e-4, atol=1e-5)
+
+
+def test_layernorm_softmax_c(dev):
+    from dc_vic_amd import ops
+    x = rnd(2, 128, 12, 20, seed=26, scale=3.0)
+    g, b = 1 + 0.1 * rnd(128, seed=27), 0.1 * rnd(128, seed=28)
+    ref = F.layer_norm(x.permute(0, 2, 3, 1), (128,), g, b, eps=1e-5).permute(0, 3, 1, 2)
+    close(ops.layernorm_c(x.to(dev), g.to(dev), b.to(dev)), ref, rtol=1e-4, atol=1e-5)
+    s = rnd(3, 200, 77, seed=29, scale=4.0)
+    out = ops.softmax_c_(s.to(dev).contiguous(), 3, 200, 77)
+    close(out, F.softmax(s, dim=1), rtol=1e-5, atol=1e-7)
+
+
+@pytest.mark.parametrize("HW,C", [(256, 64), (150, 512)])
+def test_attention_gemms(dev, HW, C):
+    """AttnBlock score/value products (ldm model.py:186-196) through bgemm + softmax_c."""
+    from dc_vic_amd import ops
+    N = 2
+    q, k, v = rnd(N, C, HW, seed=30), rnd(N, C, HW, seed=31), rnd(N, C, HW, seed=32)
+    w_ = torch.bmm(q.permute(0, 2, 1), k) * (C ** -0.5)
+    w_ = F.softmax(w_, dim=2)
+    ref = torch.bmm(v, w_.permute(0, 2, 1))
+    qkv = torch.cat([q, k, v], 1).to(dev).contiguous()       # [N, 3C, HW]
+    qd, kd, vd = qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:]
+    St = torch.empty(N, HW, HW, device=dev)
+    bs = 3 * C * HW
+    ops.bgemm(kd, (bs, 1, HW), qd, (bs, HW, 1), St, (HW * HW, HW), N, HW, HW, C, alpha=C ** -0.5)
+    ops.softmax_c_(St, N, HW, HW)
+    out = torch.empty(N, C, HW, device=dev)
+    ops.bgemm(vd, (bs, HW, 1), St, (HW * HW, HW, 1), out, (C * HW, HW), N, C, HW, HW)
+    close(out, ref, rtol=2e-4, atol=2e-5)
+
+
+@pytest.mark.parametrize("H,W,shift", [(16, 16, 0), (16, 16, 4), (8, 24, 4), (32, 32, 4)])
+def test_swin_window_attention(dev, H, W, shift):
+    from dc_vic_amd import ops
+    from oracle import dcvic_oracle as O
+    N, C, heads, ws = 2, 128, 8, 8
+    qkv = rnd(N, 3 * C, H, W, seed=33)
+    table = 0.5 * rnd(225, heads, seed=34)
+    # reference: the window-attention part of SwinTransformerBlock on the [B, L, 3C] token view
+    t = qkv.flatten(2).transpose(1, 2).view(N, H, W, 3 * C)
+    if shift:
+        t = torch.roll(t, shifts=(-shift, -shift), dims=(1, 2))
+    xw = t.view(N, H // ws, ws, W // ws, ws, 3 * C).permute(0, 1, 3, 2, 4, 5).reshape(-1, ws * ws, 3 * C)
+    B_ = xw.shape[0]
+    r = xw.reshape(B_, 64, 3, heads, C // heads).permute(2, 0, 3, 1, 4)
+    q, k, v = r[0] * 0.25, r[1], r[2]
+    attn = q @ k.transpose(-2, -1) + table[O._rel_pos_index(ws).view(-1)].view(64, 64, -1).permute(2, 0, 1).unsqueeze(0)
+    if shift:
+        mask = O._shift_mask(H, W, ws, shift)
+        nW = mask.shape[0]
+        attn = (attn.view(B_ // nW, nW, heads, 64, 64) + mask.unsqueeze(1).unsqueeze(0)).view(-1, heads, 64, 64)
+    o = (F.softmax(attn, -1) @ v).transpose(1, 2).reshape(B_, 64, C)
+    o = o.view(N, H // ws, W // ws, ws, ws, C).permute(0, 1, 3, 2, 4, 5).reshape(N, H, W, C)
+    if shift:
+        o = torch.roll(o, shifts=(shift, shift), dims=(1, 2))
+    ref = o.permute(0, 3, 1, 2)
+    out = ops.swin_attn(qkv.to(dev), table.to(dev), heads, ws, shift)
+    close(out, ref, rtol=1e-4, atol=1e-5)
+
+
+def test_elementwise(dev):
+    from dc_vic_amd import ops
+    a, b, c = rnd(2, 48, 9, 11, seed=35), rnd(2, 48, 9, 11, seed=36), rnd(2, 48, 9, 11, seed=37)
+    A, B, Cc = a.to(dev), b.to(dev), c.to(dev)
+    close(ops.add(A, B), a + b, rtol=0, atol=0)
+    close(ops.add_mul_sigmoid(A, B, Cc), a + b * torch.sigmoid(c), rtol=1e-6, atol=1e-6)
+    close(ops.sft(A, B, Cc, w=1.0), a + 1.0 * (a * b + c), rtol=1e-6, atol=1e-6)
+    close(ops.activation(A, ops.ACT_GELU), F.gelu(a), rtol=1e-5, atol=1e-6)
+    close(ops.activation(A, ops.ACT_HALF_TANH), 0.5 * torch.tanh(a), rtol=1e-5, atol=1e-6)
+    close(ops.activation(A, ops.ACT_LRELU02), F.leaky_relu(a, 0.2), rtol=0, atol=0)
+    sc, sh = rnd(2, 48, seed=38), rnd(2, 48, seed=39)
+    close(ops.chan_affine(A, sc.to(dev), sh.to(dev), add_=B), a * (1 + sc[:, :, None, None]) + sh[:, :, None, None] + b, rtol=1e-6, atol=1e-6)
+    x = rnd(2, 3, 50, 70, seed=40)
+    close(ops.pad_reflect(x.to(dev), 14, 58), F.pad(x, (0, 58, 0, 14), mode="reflect"), rtol=0, atol=0)
+    y, y8 = ops.crop_clamp((x * 1.5).to(dev), 33, 41, want_u8=True)
+    refc = (x * 1.5)[:, :, :33, :41].clamp(-1, 1)
+    close(y, refc, rtol=0, atol=0)
+    ref8 = ((refc + 1.0) / 2.0 * 255.0).numpy().transpose(0, 2, 3, 1).astype(np.uint8)
+    assert np.array_equal(y8.cpu().numpy(), ref8)
+
+
+def test_vq_argmin_index_exact(dev, synth_sd):
+    """Index-exact against the oracle's restatement of VectorQuantizer2 on two clouds (reference-init
+    codebook U(+-1/256)); disagreements, if any, must be fp32 near-ties and are itemised."""
+    from dc_vic_amd import ops
+    from oracle import dcvic_oracle as O
+    cb = synth_sd["vq_model.quantize.embedding.weight"]
+    for seed, scale, shape in ((41, 1.0, (2, 4, 64, 64)), (42, 0.01, (3, 4, 24, 40)), (43, 3.0, (1, 4, 7, 5))):
+        z = rnd(*shape, seed=seed, scale=scale)
+        zq_ref, idx_ref = O.vq_quantize({"vq_model.quantize.embedding.weight": cb}, z)
+        idx, zq, feat = ops.vq_argmin(z.to(dev), cb.to(dev), want_zq=True, want_feat=True)
+        idx_c = idx.cpu()
+        mism = (idx_c != idx_ref)
+        if mism.any():
+            # itemise: both candidates must be within 2 ulp of the minimum distance
+            zf = z.permute(0, 2, 3, 1).reshape(-1, 4).double()
+            d = (zf ** 2).sum(1, keepdim=True) + (cb.double() ** 2).sum(1) - 2 * zf @ cb.double().t()
+            m = mism.reshape(-1)
+            gap = (d[m, idx_c.reshape(-1)[m]] - d[m, idx_ref.reshape(-1)[m]]).abs()
+            assert float(gap.max()) < 1e-6 * float(d.abs().max()), "VQ mismatch that is not a near-tie"
+        assert mism.float().mean() < 1e-3
+        ok = ~mism
+        assert torch.equal(zq.cpu().permute(0, 2, 3, 1)[ok], zq_ref.permute(0, 2, 3, 1)[ok])
+        ref_feat = O.onehot_feat({}, zq.cpu(), idx_c)
+        assert torch.equal(feat.cpu(), ref_feat)
+
+
+def test_argmax_lut(dev, synth_sd):
+    from dc_vic_amd import ops
+    from oracle import dcvic_oracle as O
+    logits = rnd(2, 256, 12, 20, seed=44)
+    logits[0, 7, 3, 3] = logits[0, 200, 3, 3] = 50.0     # tie -> first maximum
+    idx, lat = ops.argmax_lut(logits.to(dev), synth_sd["vq_model.quantize.embedding.weight"].to(dev),
+                              synth_sd["vq_model.post_quant_conv.weight"].to(dev).contiguous(),
+                              synth_sd["vq_model.post_quant_conv.bias"].to(dev))
+    ref_idx = torch.argmax(logits, 1)
+    assert torch.equal(idx.cpu(), ref_idx) and int(idx[0, 3, 3]) == 7
+    ref_lat = O._conv(synth_sd, "vq_model.post_quant_conv", O.vq_indices_to_latent(synth_sd, ref_idx))
+    close(lat, ref_lat, rtol=1e-5, atol=1e-8)
+
+
+def test_gaussian_rate(dev):
+    """Symbols / cdf indexes exact, y_hat exact, likelihood and bits within fp32 erfc tolerance."""
+    from dc_vic_amd import ops
+    from oracle import entropy_oracle as eo
+    N, C, H, W = 3, 32, 16, 16
+    y = rnd(N, C, H, W, seed=45, scale=3.0)
+    mu = rnd(N, C, H, W, seed=46)
+    sigma = rnd(N, C, H, W, seed=47, scale=2.0).abs() * torch.exp(rnd(N, C, H, W, seed=48))
+    sigma[0, 0, 0, :8] = torch.tensor([0.0, 0.05, 0.11, 0.110001, 255.9, 256.0, 300.0, 1e4])
+    table = eo.get_scale_table()
+    sym_ref = torch.round(y - mu)
+    yh_ref = sym_ref + mu
+    lik_ref = eo.gc_likelihood(yh_ref, sigma, mu)
+    idx_ref = eo.gc_build_indexes(sigma)
+    yh = torch.empty(N, C, H, W, device=dev)
+    sym = torch.empty(N, C, H, W, dtype=torch.int32, device=dev)
+    ix = torch.empty(N, C, H, W, dtype=torch.int32, device=dev)
+    lik = torch.empty(N, C, H, W, device=dev)
+    bits = torch.zeros(N, device=dev)
+    ops.gaussian_rate(y.to(dev), None, mu.to(dev), sigma.to(dev), table.to(dev), yh, sym, ix, lik, bits)
+    assert torch.equal(sym.cpu(), sym_ref.int())
+    assert torch.equal(ix.cpu(), idx_ref)
+    assert torch.equal(yh.cpu(), yh_ref)
+    close(lik, lik_ref, rtol=2e-4, atol=1e-9)
+    bits_ref = -(torch.log(lik_ref).reshape(N, -1).double().sum(1)) / np.log(2)
+    close(bits, bits_ref, rtol=1e-5, atol=1e-3)
+    # decode mode reproduces y_hat bit-exactly from the symbols
+    yh2 = torch.empty(N, C, H, W, device=dev)
+    ops.gaussian_rate(None, sym, mu.to(dev), sigma.to(dev), table.to(dev), yh2, None, None, None, None)
+    assert torch.equal(yh2, yh)
+
+
+def test_eb_rate(dev, synth_sd):
+    from dc_vic_amd import ops
+    from dc_vic_amd.entropy import pack_entropy_bottleneck
+    from oracle import entropy_oracle as eo
+    eb = eo.EntropyBottleneckOracle(synth_sd, "entropy_model_z")
+    z = rnd(2, 192, 4, 6, seed=49, scale=4.0)
+    zh_ref, lik_ref = eb.forward(z)
+    packs = pack_entropy_bottleneck({k: v.to(dev) for k, v in synth_sd.items() if k.startswith("entropy_model_z.")}, "entropy_model_z")
+    zh = torch.empty(2, 192, 4, 6, device=dev)
+    sym = torch.empty(2, 192, 4, 6, dtype=torch.int32, device=dev)
+    lik = torch.empty(2, 192, 4, 6, device=dev)
+    bits = torch.zeros(2, device=dev)
+    ops.eb_rate(z.to(dev), packs, zh, sym, lik, bits)
+    assert torch.equal(zh.cpu(), zh_ref)
+    assert torch.equal(sym.cpu(), eb.symbols(z))
+    close(lik, lik_ref, rtol=2e-4, atol=1e-8)
+    close(bits, -(torch.log(lik_ref).reshape(2, -1).double().sum(1)) / np.log(2), rtol=1e-5, atol=1e-3)
