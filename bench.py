@@ -1,0 +1,181 @@
+#!/usr/bin/env python3
+"""bench.py -- images/s of DC-VIC encode+decode at 256x256, q=0, on N x MI355X (BASELINE.json metric).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B] [--no-cpu-baseline]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+One "step" = one pass of the hot path over one batch of B=32 synthetic 256x256 images that are already
+resident in HBM: compress_batch (VQGAN encoder -> VQ search -> ELIC encoder -> hyper-encoder ->
+hyper-decoder + CHARM -> symbols -> host rANS -> 3 byte strings per image) followed by decompress_batch
+(host rANS decode interleaved with the GPU-resident CHARM -> ELIC decoder features -> Swin estimator ->
+argmax LUT -> SFT-fused VQGAN decoder -> crop/clamp), i.e. real bytes are produced and consumed.
+Images shard across GPUs (weak scaling: B per GPU); RCCL only all-gathers the per-image rate table.
+Weights: deterministic synthetic (dc_vic_amd.synth) -- no checkpoint can be fetched offline.
+
+Output: ONE JSON line on rank 0 (contract in the task statement) with `roofline` for the dominant
+kernel (HIP-event timed inside the timed region) and `cpu_baseline` (the CPU oracle on the host cores).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+PEAK_F32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: dense fp32 matrix peak (v_mfma_f32_32x32x2_f32)
+GFLOP_PER_IMAGE = 1009.6         # one 256x256 image, compress + decompress
+
+
+def parse():
+    p = argparse.ArgumentParser()
+    p.add_argument("--gpus", type=int, default=1)
+    p.add_argument("--steps", type=int, default=3)
+    p.add_argument("--warmup", type=int, default=1)
+    p.add_argument("--batch", type=int, default=32)
+    p.add_argument("--quality", type=int, default=0)
+    p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--no-kernel-events", action="store_true", help="skip the per-launch HIP events (roofline becomes null)")
+    return p.parse_args()
+
+
+def cpu_baseline(sd, quality: int):
+    """The oracle (CPU restatement of the reference's path) on this host's cores, bounded sample."""
+    from oracle.dcvic_oracle import Oracle
+    try:
+        cores = len(os.sched_getaffinity(0))      # the box's CPU share, not the host's core count
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    cores = max(1, min(cores, int(os.environ.get("DCVIC_CPU_BASELINE_THREADS", "16"))))
+    torch.set_num_threads(cores)
+    orc = Oracle(sd)
+    g = torch.Generator().manual_seed(99)
+    x = torch.rand((1, 3, 256, 256), generator=g) * 2 - 1
+    r = orc.compress(x, quality)           # warm-up (first-call allocations)
+    orc.decompress(r["string_list"])
+    n = 2
+    t0 = time.perf_counter()
+    for i in range(n):
+        r = orc.compress(x, quality)
+        orc.decompress(r["string_list"])
+    dt = time.perf_counter() - t0
+    return {"value": n / dt, "unit": "images/s", "cores": cores, "kind": "port",
+            "sample": f"{n} x (compress+decompress) of one 256x256 image, q={quality}, torch {torch.__version__} fp32 CPU oracle, "
+                      f"{cores} threads, after 1 warm-up"}
+
+
+def main():
+    a = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != a.gpus and world > 1:
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device (the path has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist_
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist_.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        dist = dist_
+
+    from dc_vic_amd import BaseConfig, build_comp_model, ops
+    from dc_vic_amd.parallel import gather_rate_table
+    from dc_vic_amd.synth import load_synth_weights
+
+    opt = BaseConfig.fromfile(os.path.join(ROOT, "config", "dc_vic_synthetic.yaml"), {"device": str(dev)})
+    model = build_comp_model(opt)
+    sd = load_synth_weights(model, 1234)
+    model.codec_setup()
+
+    B = a.batch
+    g = torch.Generator().manual_seed(1000 + rank)            # every rank codes its own shard
+    x = (torch.rand((B, 3, 256, 256), generator=g) * 2 - 1).to(dev)
+
+    def step():
+        r = model.compress_batch(x, a.quality)
+        imgs, _, _ = model.decompress_batch(r["string_lists"])
+        real_bits = np.array([8.0 * sum(len(s) for s in sl) + 32 * 3 for sl in r["string_lists"]])   # + 3 uint32 length prefixes
+        table = np.stack([real_bits, r["pred_y_bit"] + r["pred_z_bit"]], axis=1)
+        table = gather_rate_table(table, dist, dev)
+        return imgs, table
+
+    def sync():
+        torch.cuda.synchronize(dev)
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize(dev)
+
+    def log(msg):
+        if rank == 0:
+            print(f"[bench] {msg}", file=sys.stderr, flush=True)
+
+    t_w = time.perf_counter()
+    for _ in range(a.warmup):
+        step()
+    sync()
+    log(f"model ready, {a.warmup} warm-up step(s) in {time.perf_counter() - t_w:.2f}s")
+    if not a.no_kernel_events:
+        ops.kernel_events_start()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        imgs, table = step()
+    sync()
+    dt = time.perf_counter() - t0
+    log(f"{a.steps} timed step(s) in {dt:.2f}s")
+    ev = ops.kernel_events_stop() if not a.no_kernel_events else None
+
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    if rank == 0:
+        n_img = world * B * a.steps
+        value = n_img / dt
+        avg_bpp = float(table[:, 0].mean() / (256 * 256))
+        out = {
+            "metric": "images/sec encode+decode @256x256 q=0", "value": value, "unit": "images/s", "n_gpus": world,
+            "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * dt / a.steps, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"dc_vic_patchgan.yaml architecture, synthetic random 256x256, batch={B}/GPU, q={a.quality}, "
+                                   "compress_batch+decompress_batch through real rANS bytes, synthetic weights",
+                       "batch_per_gpu": B, "quality": a.quality, "image": "256x256", "parallelism": f"dp{world} (images sharded, RCCL all_gather of the rate table)"},
+            "avg_bpp": avg_bpp,
+            "avg_pred_bpp": float(table[:, 1].mean() / (256 * 256)),
+            "end_to_end_frac_of_f32_mfma_peak": value / world * GFLOP_PER_IMAGE / 1e3 / PEAK_F32_MFMA_TFLOPS,
+        }
+        if ev:
+            k = max(ev.values(), key=lambda d: d["time_s"])
+            out["roofline"] = {"bound": "mfma", "kernel": k["kernel"], "achieved": k["flops"] / k["time_s"] / 1e12,
+                               "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": k["flops"] / k["time_s"] / 1e12 / PEAK_F32_MFMA_TFLOPS,
+                               "traffic": None, "launches": k["launches"], "avg_launch_us": 1e6 * k["time_s"] / k["launches"],
+                               "gflop_per_launch": k["flops"] / k["launches"] / 1e9,
+                               "share_of_step_time": k["time_s"] / dt,
+                               "all_conv_kernels": {n: {"tflops": d["flops"] / d["time_s"] / 1e12, "launches": d["launches"],
+                                                        "time_share": d["time_s"] / dt} for n, d in ev.items()}}
+        else:
+            out["roofline"] = None
+        if world == 1 and not a.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(sd, a.quality)
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -95,8 +95,8 @@ class Minnen20CharmContextModel(nn.Module):
                 ops.gaussian_rate(y[:, sl], None, mu, sigma, table, yq, sym[:, sl] if need_sym else None,
                                   idx[:, sl] if need_sym else None, lik[:, sl] if lik is not None else None, bits_out)
             else:
-                ops.gaussian_rate(None, torch.zeros((N, sc, H, W), dtype=torch.int32, device=dev), mu, sigma, table, None, None,
-                                  idx[:, sl], None, None)
+                # index-only pass (sym_in is a placeholder here: no y_hat / likelihood output is requested)
+                ops.gaussian_rate(None, sym[:, sl], mu, sigma, table, None, None, idx[:, sl], None, None)
                 s_i = symbols_in(i, idx[:, sl])
                 sym[:, sl] = s_i
                 ops.gaussian_rate(None, sym[:, sl], mu, sigma, table, yq, None, None, None, None)

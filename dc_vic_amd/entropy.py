@@ -42,7 +42,11 @@ def host_threads() -> int:
     env = os.environ.get("DCVIC_HOST_THREADS")
     if env:
         return max(1, int(env))
-    return max(1, min(16, (os.cpu_count() or 1)))
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    return max(1, min(16, n))
 
 
 def _pmf_to_cdf(pmf: Tensor, tail_mass: Tensor, pmf_length: Tensor, max_length: int) -> np.ndarray:

@@ -42,6 +42,33 @@ def new(N, Cc, H, W, like: Tensor) -> Tensor:
     return torch.empty((N, Cc, H, W), dtype=torch.float32, device=like.device)
 
 
+# ------------------------------------------------------------------------------------------- kernel events
+# Per-launch HIP events on the stream the conv kernels run on (torch's current stream), used by
+# bench.py to report the dominant kernel's achieved TFLOP/s inside the timed region.
+_EVENTS = None
+CONV_KERNEL_NAMES = {0: "conv_mfma_kernel<2,4,2,2>", 1: "conv_mfma_kernel<2,2,1,4>", 2: "conv_mfma_kernel<1,2,1,4>",
+                     3: "conv_mfma_kernel<3,2,1,4>"}
+
+
+def kernel_events_start() -> None:
+    global _EVENTS
+    _EVENTS = []
+
+
+def kernel_events_stop():
+    """-> {kernel name: {kernel, launches, flops (algorithmic 2*MAC), time_s}}; call after a device sync."""
+    global _EVENTS
+    ev, _EVENTS = _EVENTS, None
+    out = {}
+    for cfg, flops, e0, e1 in ev or []:
+        name = CONV_KERNEL_NAMES.get(cfg, f"conv cfg {cfg}")
+        d = out.setdefault(name, {"kernel": name, "launches": 0, "flops": 0.0, "time_s": 0.0})
+        d["launches"] += 1
+        d["flops"] += flops
+        d["time_s"] += e0.elapsed_time(e1) * 1e-3
+    return out
+
+
 # ------------------------------------------------------------------------------------------- conv
 class ConvPlan:
     """A convolution layer bound to the C ABI: descriptor(s) + packed weights.
@@ -153,7 +180,14 @@ class ConvPlan:
                 io.Hout, io.Wout = Hf, Wf
                 io.osy = io.osx = 1
                 io.ooy = io.oox = 0
-            check(lib().dcvic_conv2d_f32(C.byref(d), _p(packed), C.byref(io), st), "conv2d")
+            if _EVENTS is not None:
+                e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+                e0.record()
+                check(lib().dcvic_conv2d_f32(C.byref(d), _p(packed), C.byref(io), st), "conv2d")
+                e1.record()
+                _EVENTS.append((int(d.cfg), 2.0 * N * io.Hout * io.Wout * self.Cout * self.Cin * int(d.T), e0, e1))
+            else:
+                check(lib().dcvic_conv2d_f32(C.byref(d), _p(packed), C.byref(io), st), "conv2d")
         return out
 
 
