@@ -135,6 +135,8 @@ def main():
     dt = time.perf_counter() - t0
     log(f"{a.steps} timed step(s) in {dt:.2f}s")
     ev = ops.kernel_events_stop() if not a.no_kernel_events else None
+    if ev and rank == 0 and os.environ.get("DCVIC_BENCH_DETAIL"):
+        print(ops.shape_stats_report(), file=sys.stderr, flush=True)
 
     if dist is not None:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)

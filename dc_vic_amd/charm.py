@@ -13,6 +13,8 @@ from __future__ import annotations
 
 from typing import Callable, List, Optional, Tuple
 
+import os
+
 import numpy as np
 import torch
 import torch.nn as nn
@@ -82,14 +84,31 @@ class Minnen20CharmContextModel(nn.Module):
         sym = torch.empty((N, Cy, H, W), dtype=torch.int32, device=dev) if need_sym else None
         idx = torch.empty((N, Cy, H, W), dtype=torch.int32, device=dev) if need_sym else None
         table = entropy_model_y._table_dev(hyper_out)
+        main = torch.cuda.current_stream(dev) if dev.type == "cuda" else None
+        side = None
+        if main is not None and os.environ.get("DCVIC_CHARM_STREAMS", "1") != "0":
+            if getattr(self, "_side_stream", None) is None or self._side_stream.device != dev:
+                self._side_stream = torch.cuda.Stream(device=dev)
+            side = self._side_stream
         for i in range(ns):
             sl = slice(i * sc, (i + 1) * sc)
             k = self._n_support(i)
             support = [y_hat[:, : k * sc]] if k > 0 else []
             mu = ms[:, sl]
             sigma = ms[:, Cy + i * sc: Cy + (i + 1) * sc]
-            self.mean_slice_transforms[i]([hyper_mean] + support, out=mu)
-            self.scale_slice_transforms[i]([hyper_scale] + support, out=sigma)
+            # the mean and scale transforms of a slice are independent: run them on two HIP streams so the
+            # small 16x16-map launches of both fill the chip together
+            if side is not None:
+                ev_fork = torch.cuda.Event(); ev_fork.record(main)
+                side.wait_event(ev_fork)
+                with torch.cuda.stream(side):
+                    self.scale_slice_transforms[i]([hyper_scale] + support, out=sigma)
+                    ev_join = torch.cuda.Event(); ev_join.record(side)
+                self.mean_slice_transforms[i]([hyper_mean] + support, out=mu)
+                main.wait_event(ev_join)
+            else:
+                self.mean_slice_transforms[i]([hyper_mean] + support, out=mu)
+                self.scale_slice_transforms[i]([hyper_scale] + support, out=sigma)
             yq = torch.empty((N, sc, H, W), dtype=torch.float32, device=dev)    # round(y-mu)+mu before the LRP
             if y is not None:
                 ops.gaussian_rate(y[:, sl], None, mu, sigma, table, yq, sym[:, sl] if need_sym else None,

@@ -6,16 +6,20 @@
 // GEMM view:   D[co][pixel] = sum_{ci,tap} Wt[tap][ci][co] * X[ci][pixel + tap]
 //   A operand = weights (rows = output channels), B operand = input pixels (cols), so that the
 //   accumulator's lane axis is the pixel axis and NCHW stores are 128-B row segments.
-// Data movement per workgroup (256 threads = 4 waves) and K-chunk of 8 input channels:
-//   * the input PATCH (tile + halo, all taps) of the 8 channels is staged once into LDS, zero padded
-//     (coalesced reads of NCHW rows), and re-used by every tap -> each input element is read from
-//     HBM/L2 once per output-channel tile instead of once per tap;
-//   * the pre-packed weight slab [tap][8][TC] is a linear float4 copy into LDS;
+// Data movement per workgroup (256 threads = 4 waves) and stage of CPS x 8 input channels:
+//   * the input PATCH (tile + halo, all taps) of the channels is staged once into LDS, zero padded
+//     (coalesced reads of NCHW rows, 8 independent loads in flight per lane), and re-used by every
+//     tap -> each input element is read from HBM/L2 once per output-channel tile, not once per tap;
+//   * the pre-packed weight slabs [tap][8][TC] are linear float4 copies into LDS;
 //   * every wave then issues MT x NT MFMA 32x32x2 per (tap, channel pair) with operands fetched by
 //     conflict-free ds_read_b32 (consecutive lanes -> consecutive words).
+// Tile variants (TC output channels x P pixels per workgroup) are picked per launch so that small
+// feature maps (16x16 CHARM / hyperprior maps, N=1 decoding) still fill the 256 CUs; 1x1 convolutions
+// stage several channel chunks per barrier pair.  Blocks are remapped so that the blocks sharing an
+// XCD (b % 8) walk contiguous tiles: co-tiles of one patch hit the same L2.
 // The fp32 MFMA is a k-ordered fmaf chain, so the reduction order of an output element is
-// (chunk asc, tap asc, channel asc) for every tile configuration, grid and batch size:
-// results are deterministic and batch-invariant (needed for encoder/decoder agreement).
+// (chunk asc, tap asc, channel asc) for EVERY variant, grid and batch size: results are deterministic,
+// batch-invariant and identical across variants (needed for encoder/decoder agreement).
 #include "common.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -23,11 +27,11 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #define KC 8
 #define MAXSLOT 6
 #define NTHREADS 256
+#define NXCD 8
 
 struct ConvKArgs {
-    int Cin, Cout, T, stride, ups;
+    int Cin, Cout, T, stride;
     int N, H, W, Hout, Wout, Hfull, Wfull, osy, osx, ooy, oox;
-    int n_src;
     const float* src[DCVIC_MAX_SRC];
     int srcC[DCVIC_MAX_SRC];
     long long src_bs[DCVIC_MAX_SRC];
@@ -41,19 +45,21 @@ struct ConvKArgs {
     const float* afft;
     long long aff_bs;
     const float* wp;
-    int tap[DCVIC_MAX_TAPS];  // (dy & 0xffff) | (dx << 16)
+    int TX, dy0, dx0, dstep;  // taps form a grid: t = iy*TX + ix, dy = dy0 + iy*dstep, dx = dx0 + ix*dstep
+    int nslots;               // ceil(plane / NTHREADS)
     int TWlog, tiles_x, tiles_y;
     int PH, PW, plane, dy_min, dx_min;
-    int TG, n_chunks, n_cotiles;
+    int TG, CPS, n_chunks, n_cotiles;
+    int nblocks;
 };
 
-template <int MT, int NT, int WM, int WN>
-__global__ __launch_bounds__(NTHREADS, 2) void conv_mfma_kernel(const ConvKArgs K) {
+template <int MT, int NT, int WM, int WN, bool UPS>
+__global__ __launch_bounds__(NTHREADS, (MT * NT >= 8) ? 2 : ((MT * NT >= 4) ? 3 : 4)) void conv_mfma_kernel(const ConvKArgs K) {
     constexpr int TC = WM * MT * 32;
     constexpr int P = WN * NT * 32;
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* Xs = smem;                                  // [KC][plane]
-    float* Ws = smem + ((KC * K.plane + 3) & ~3);      // [TG][KC][TC]
+    float* Xs = smem;                                            // [CPS*KC][plane]
+    float* Ws = smem + ((K.CPS * KC * K.plane + 3) & ~3);        // [slabs][KC][TC]
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -61,8 +67,14 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_mfma_kernel(const ConvKArgs 
     const int wm = wave / WN, wn = wave % WN;
     const int lane_k = lane >> 5, lane_j = lane & 31;
 
-    // block -> (n, tile_y, tile_x, cotile); cotile fastest so that co-tiles of one patch run together
-    int b = blockIdx.x;
+    // XCD-aware remap (bijective): blocks b and b+8 share an XCD -> give each XCD a contiguous range
+    int b;
+    {
+        const int orig = blockIdx.x, nb = K.nblocks;
+        const int q = nb / NXCD, r = nb % NXCD, x = orig % NXCD;
+        b = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + orig / NXCD;
+    }
+    // block -> (n, tile_y, tile_x, cotile); cotile fastest: co-tiles of one patch run back to back
     const int cotile = b % K.n_cotiles; b /= K.n_cotiles;
     const int tile_x = b % K.tiles_x; b /= K.tiles_x;
     const int tile_y = b % K.tiles_y; b /= K.tiles_y;
@@ -73,30 +85,17 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_mfma_kernel(const ConvKArgs 
 
     // patch origin in input coordinates
     int iy0, ix0;
-    if (K.ups) { iy0 = (oy0 + K.dy_min) >> 1; ix0 = (ox0 + K.dx_min) >> 1; }
+    if (UPS) { iy0 = (oy0 + K.dy_min) >> 1; ix0 = (ox0 + K.dx_min) >> 1; }
     else { iy0 = oy0 * K.stride + K.dy_min; ix0 = ox0 * K.stride + K.dx_min; }
 
-    // per-thread patch slots (identical for every channel / chunk)
-    int goff[MAXSLOT];
-#pragma unroll
-    for (int s = 0; s < MAXSLOT; ++s) {
-        const int r = tid + s * NTHREADS;
-        int g = -1;
-        if (r < K.plane) {
-            const int py = r / K.PW, px = r - py * K.PW;
-            const int iy = iy0 + py, ix = ix0 + px;
-            if (iy >= 0 && iy < K.H && ix >= 0 && ix < K.W) g = iy * K.W + ix;
-        }
-        goff[s] = g;
-    }
-
-    // per-lane pixel coordinates of each B fragment
-    int pty[NT], ptx[NT];
+    // per-lane pixel coordinates / LDS base offsets of each B fragment
+    int pty[NT], ptx[NT], bbase[NT];
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
         const int p = (wn * NT + nt) * 32 + lane_j;
         pty[nt] = p >> K.TWlog;
         ptx[nt] = p & (TW - 1);
+        bbase[nt] = (pty[nt] * K.stride) * K.PW + ptx[nt] * K.stride + lane_k * K.plane;
     }
 
     f32x16 acc[MT][NT];
@@ -110,67 +109,91 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_mfma_kernel(const ConvKArgs 
     const long long HW = (long long)K.H * K.W;
     const float* wbase = K.wp + (long long)cotile * K.n_chunks * K.T * (KC * TC);
 
-    for (int chunk = 0; chunk < K.n_chunks; ++chunk) {
-        // ---- stage the input patch of channels [c0, c0+8)
-        const int c0 = chunk * KC;
+    for (int chunk0 = 0; chunk0 < K.n_chunks; chunk0 += K.CPS) {
+        const int ncs = min(K.CPS, K.n_chunks - chunk0);
+        // ---- stage the input patch of channels [chunk0*8, (chunk0+ncs)*8): branch-free, 8 loads in flight
+        for (int cs = 0; cs < ncs; ++cs) {
+            const int c0 = (chunk0 + cs) * KC;
+            const float* cp[KC];
+            bool cok[KC];
 #pragma unroll
-        for (int k = 0; k < KC; ++k) {
-            int c = c0 + k;
-            const float* p = nullptr;
-            if (c < K.Cin) {
+            for (int k = 0; k < KC; ++k) {
+                int c = c0 + k;
+                cok[k] = c < K.Cin;
                 int si = 0;
-                if (c >= K.srcC[0]) { c -= K.srcC[0]; si = 1; if (c >= K.srcC[1]) { c -= K.srcC[1]; si = 2; } }
-                p = K.src[si] + (long long)n * K.src_bs[si] + (long long)c * HW;
-            }
-#pragma unroll
-            for (int s = 0; s < MAXSLOT; ++s) {
-                const int r = tid + s * NTHREADS;
-                if (r < K.plane) {
-                    float v = 0.f;
-                    if (p != nullptr && goff[s] >= 0) v = p[goff[s]];
-                    Xs[k * K.plane + r] = v;
+                if (cok[k]) {
+                    if (c >= K.srcC[0]) { c -= K.srcC[0]; si = 1; if (c >= K.srcC[1]) { c -= K.srcC[1]; si = 2; } }
+                } else {
+                    c = 0;
                 }
+                cp[k] = K.src[si] + (long long)n * K.src_bs[si] + (long long)c * HW;
+            }
+            float* xdst = Xs + cs * (KC * K.plane);
+            for (int s = 0; s < K.nslots; ++s) {
+                const int r = min(tid + s * NTHREADS, K.plane - 1);   // surplus lanes duplicate the last element (same value)
+                const int py = r / K.PW, px = r - py * K.PW;
+                const int iy = iy0 + py, ix = ix0 + px;
+                const bool inb = (iy >= 0) & (iy < K.H) & (ix >= 0) & (ix < K.W);
+                const int g = inb ? iy * K.W + ix : 0;
+                float v[KC];
+#pragma unroll
+                for (int k = 0; k < KC; ++k) v[k] = cp[k][g];
+#pragma unroll
+                for (int k = 0; k < KC; ++k) xdst[k * K.plane + r] = (inb && cok[k]) ? v[k] : 0.f;
             }
         }
         for (int tg = 0; tg < K.T; tg += K.TG) {
             const int ntap = min(K.TG, K.T - tg);
-            // ---- stage the weight slab [ntap][KC][TC] (linear copy)
+            const int nslab = (K.TG >= K.T) ? ncs * K.T : ntap;      // CPS > 1 only when all taps fit one stage
+            // ---- stage the weight slabs [nslab][KC][TC]: linear float4 copy, three slabs in flight per thread
             {
-                const float4* wsrc = reinterpret_cast<const float4*>(wbase + ((long long)chunk * K.T + tg) * (KC * TC));
+                constexpr int VPT = KC * TC / 4;   // float4 per slab
+                const float4* wsrc = reinterpret_cast<const float4*>(wbase + ((long long)chunk0 * K.T + tg) * (KC * TC));
                 float4* wdst = reinterpret_cast<float4*>(Ws);
-                const int nvec = ntap * (KC * TC / 4);
-                for (int i = tid; i < nvec; i += NTHREADS) wdst[i] = wsrc[i];
+                if (VPT >= NTHREADS || tid < VPT) {
+                    for (int t0 = 0; t0 < nslab; t0 += 3) {
+                        float4 w[3];
+                        int tt[3];
+#pragma unroll
+                        for (int j = 0; j < 3; ++j) { tt[j] = min(t0 + j, nslab - 1); w[j] = wsrc[tt[j] * VPT + tid]; }
+#pragma unroll
+                        for (int j = 0; j < 3; ++j) wdst[tt[j] * VPT + tid] = w[j];
+                    }
+                }
             }
             __syncthreads();
-            for (int tt = 0; tt < ntap; ++tt) {
-                const int tp = K.tap[tg + tt];
-                const int dy = (int)(short)(tp & 0xffff), dx = tp >> 16;
-                int boff[NT];
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt) {
-                    int row, col;
-                    if (K.ups) {
-                        row = ((oy0 + pty[nt] + dy) >> 1) - iy0;
-                        col = ((ox0 + ptx[nt] + dx) >> 1) - ix0;
-                    } else {
-                        row = pty[nt] * K.stride + dy - K.dy_min;
-                        col = ptx[nt] * K.stride + dx - K.dx_min;
-                    }
-                    boff[nt] = row * K.PW + col + lane_k * K.plane;
-                }
-                const float* As = Ws + (tt * KC + lane_k) * TC + wm * (MT * 32) + lane_j;
-#pragma unroll
-                for (int ks = 0; ks < KC / 2; ++ks) {
-                    float a[MT], bb[NT];
-#pragma unroll
-                    for (int mt = 0; mt < MT; ++mt) a[mt] = As[(2 * ks) * TC + mt * 32];
-#pragma unroll
-                    for (int nt = 0; nt < NT; ++nt) bb[nt] = Xs[boff[nt] + (2 * ks) * K.plane];
-#pragma unroll
-                    for (int mt = 0; mt < MT; ++mt)
+            for (int cs = 0; cs < ncs; ++cs) {
+                const float* xb0 = Xs + cs * (KC * K.plane);
+                int tiy = tg / K.TX, tix = tg - tiy * K.TX;
+                for (int tt = 0; tt < ntap; ++tt) {
+                    const int dy = K.dy0 + tiy * K.dstep, dx = K.dx0 + tix * K.dstep;
+                    if (++tix == K.TX) { tix = 0; ++tiy; }
+                    int boff[NT];
+                    const float* xb;
+                    if (UPS) {
+                        xb = xb0;
 #pragma unroll
                         for (int nt = 0; nt < NT; ++nt)
-                            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mt], bb[nt], acc[mt][nt], 0, 0, 0);
+                            boff[nt] = (((oy0 + pty[nt] + dy) >> 1) - iy0) * K.PW + (((ox0 + ptx[nt] + dx) >> 1) - ix0) + lane_k * K.plane;
+                    } else {
+                        xb = xb0 + (dy - K.dy_min) * K.PW + (dx - K.dx_min);   // uniform tap offset
+#pragma unroll
+                        for (int nt = 0; nt < NT; ++nt) boff[nt] = bbase[nt];
+                    }
+                    const float* As = Ws + ((cs * ntap + tt) * KC + lane_k) * TC + wm * (MT * 32) + lane_j;
+#pragma unroll
+                    for (int ks = 0; ks < KC / 2; ++ks) {
+                        float a[MT], bb[NT];
+#pragma unroll
+                        for (int mt = 0; mt < MT; ++mt) a[mt] = As[(2 * ks) * TC + mt * 32];
+#pragma unroll
+                        for (int nt = 0; nt < NT; ++nt) bb[nt] = xb[boff[nt] + (2 * ks) * K.plane];
+#pragma unroll
+                        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                            for (int nt = 0; nt < NT; ++nt)
+                                acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mt], bb[nt], acc[mt][nt], 0, 0, 0);
+                    }
                 }
             }
             __syncthreads();
@@ -229,18 +252,38 @@ __global__ void conv_pack_kernel(const float* __restrict__ w, float* __restrict_
 }
 
 // ------------------------------------------------------------------------------------------------
-// tile configurations
-struct TileCfg { int MT, NT, WM, WN; };
-static const TileCfg kCfgs[] = {
-    {2, 4, 2, 2},  // 0: TC 128, P 256
-    {2, 2, 1, 4},  // 1: TC 64,  P 256
-    {1, 2, 1, 4},  // 2: TC 32,  P 256
-    {3, 2, 1, 4},  // 3: TC 96,  P 256
-};
-static inline int cfg_TC(int c) { return kCfgs[c].WM * kCfgs[c].MT * 32; }
-static inline int cfg_P(int c) { return kCfgs[c].WN * kCfgs[c].NT * 32; }
+// tile variants: desc.cfg = TC class (fixes the weight pack), the pixel-tile size P is chosen per launch
+static const int kClassTC[4] = {128, 64, 32, 96};
+static const int kClassNP[4] = {3, 3, 2, 2};
+static const int kClassP[4][3] = {{256, 128, 64}, {256, 128, 64}, {256, 128, 0}, {256, 128, 0}};
+static inline int cfg_TC(int c) { return kClassTC[c]; }
 
-static int choose_cfg(int Cout) {
+static int g_num_cu = 0;
+
+static int tile_width_log(int Wout) {
+    int TWlog = 5;
+    while (TWlog > 2 && (1 << TWlog) > Wout && (1 << (TWlog - 1)) >= Wout) --TWlog;
+    return TWlog;
+}
+
+// Expected relative throughput of a (TC class, P) variant on a launch: useful fraction of the output-channel
+// tiles x how well the grid fills the CUs x a tile-efficiency prior (bigger tiles amortise staging better).
+static double variant_score(int cls, int P, int Cout, int N, int Hout, int Wout, int upsample, int num_cu) {
+    if (P <= 0) return -1.0;
+    const int TC = kClassTC[cls];
+    const int TW = 1 << tile_width_log(Wout);
+    const int TH = P / TW;
+    if (TH < 1 || (upsample && (TH & 1))) return -1.0;
+    const int cot = (Cout + TC - 1) / TC;
+    const double wg = (double)N * ((Hout + TH - 1) / TH) * ((Wout + TW - 1) / TW) * cot;
+    const double useful = (double)Cout / (cot * TC) * ((double)Hout * Wout) / ((double)((Hout + TH - 1) / TH) * TH * ((Wout + TW - 1) / TW) * TW);
+    const double fill = wg >= 1.5 * num_cu ? 1.0 : wg / (1.5 * num_cu);
+    const double effP = P == 256 ? 1.0 : (P == 128 ? 0.93 : 0.85);
+    const double effC = TC == 128 ? 1.0 : (TC == 96 ? 0.97 : (TC == 64 ? 0.93 : 0.80));
+    return useful * fill * effP * effC;
+}
+
+static int choose_class(int Cout) {
     if (Cout <= 32) return 2;
     if (Cout <= 64) return 1;
     if (Cout == 96 || Cout == 192) return 3;
@@ -263,7 +306,7 @@ extern "C" int dcvic_conv_desc_init(dcvic_conv_desc* d, int Cin, int Cout, int K
             d->tap_ky[t] = (int8_t)ky; d->tap_kx[t] = (int8_t)kx;
             d->tap_dy[t] = (int8_t)(ky - pad_t); d->tap_dx[t] = (int8_t)(kx - pad_l);
         }
-    d->cfg = choose_cfg(Cout);
+    d->cfg = choose_class(Cout);
     return DCVIC_OK;
 }
 
@@ -292,7 +335,7 @@ extern "C" int dcvic_convT_phase_desc(dcvic_conv_desc* d, int Cin, int Cout, int
         DCVIC_CHECK_ARG(false, "convT kernel %d unsupported", k);
     }
     d->T = t;
-    d->cfg = choose_cfg(Cout);
+    d->cfg = choose_class(Cout);
     return DCVIC_OK;
 }
 
@@ -306,9 +349,10 @@ extern "C" size_t dcvic_conv_packed_bytes(const dcvic_conv_desc* d) {
 
 extern "C" int dcvic_conv_pack_f32(const dcvic_conv_desc* d, const float* w, float* packed, void* stream) {
     DCVIC_CHECK_ARG(d && w && packed, "conv_pack: null pointer");
+    DCVIC_CHECK_ARG(d->cfg >= 0 && d->cfg <= 3, "conv_pack: bad cfg %d", d->cfg);
     const int TC = cfg_TC(d->cfg);
     const long long total = (long long)n_cotiles_of(d) * n_chunks_of(d) * d->T * KC * TC;
-    // the tap->kernel index table travels through a tiny device buffer owned by the caller's stream
+    // the tap->kernel index table travels through a tiny device buffer; pack is a load-time operation
     int h_tapk[2 * DCVIC_MAX_TAPS];
     for (int t = 0; t < d->T; ++t) { h_tapk[2 * t] = d->tap_ky[t]; h_tapk[2 * t + 1] = d->tap_kx[t]; }
     int* d_tapk = nullptr;
@@ -317,23 +361,47 @@ extern "C" int dcvic_conv_pack_f32(const dcvic_conv_desc* d, const float* w, flo
     conv_pack_kernel<<<dcvic_cdiv(total, 256), 256, 0, (hipStream_t)stream>>>(w, packed, d->Cin, d->Cout, d->T, d->KH, d->KW,
                                                                         d->transposed_weight, TC, n_chunks_of(d), total, d_tapk);
     hipError_t e = hipGetLastError();
-    hipStreamSynchronize((hipStream_t)stream);  // pack is a load-time operation; keeps d_tapk's lifetime simple
+    hipStreamSynchronize((hipStream_t)stream);
     hipFree(d_tapk);
     if (e != hipSuccess) { dcvic_set_error("conv_pack: %s", hipGetErrorString(e)); return DCVIC_ELAUNCH; }
     return DCVIC_OK;
 }
 
 template <int MT, int NT, int WM, int WN>
-static int launch_cfg(const ConvKArgs& K, int blocks, size_t lds, hipStream_t st) {
+static int launch_variant(const ConvKArgs& K, bool ups, size_t lds, hipStream_t st) {
     static bool attr_set = false;
-    auto kern = conv_mfma_kernel<MT, NT, WM, WN>;
+    auto k0 = conv_mfma_kernel<MT, NT, WM, WN, false>;
+    auto k1 = conv_mfma_kernel<MT, NT, WM, WN, true>;
     if (!attr_set) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(k0), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(k1), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
-    kern<<<blocks, NTHREADS, lds, st>>>(K);
+    if (ups) k1<<<K.nblocks, NTHREADS, lds, st>>>(K);
+    else k0<<<K.nblocks, NTHREADS, lds, st>>>(K);
     DCVIC_CHECK_LAUNCH("conv2d");
     return DCVIC_OK;
+}
+
+static void init_num_cu() {
+    if (g_num_cu == 0) {
+        int dev = 0, cu = 0;
+        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cu > 0) g_num_cu = cu;
+        else g_num_cu = 256;
+    }
+}
+
+extern "C" int dcvic_conv_select_class(const dcvic_conv_desc* d, int N, int Hout, int Wout) {
+    if (!d || N <= 0 || Hout <= 0 || Wout <= 0) return DCVIC_EINVAL;
+    init_num_cu();
+    int best_cls = choose_class(d->Cout);
+    double best = -1.0;
+    for (int cls = 0; cls < 4; ++cls)
+        for (int pi = 0; pi < kClassNP[cls]; ++pi) {
+            const double sc = variant_score(cls, kClassP[cls][pi], d->Cout, N, Hout, Wout, d->upsample, g_num_cu);
+            if (sc > best + 1e-9) { best = sc; best_cls = cls; }
+        }
+    return best_cls;
 }
 
 extern "C" int dcvic_conv2d_f32(const dcvic_conv_desc* d, const float* packed, const dcvic_conv_io* io, void* stream) {
@@ -354,37 +422,59 @@ extern "C" int dcvic_conv2d_f32(const dcvic_conv_desc* d, const float* packed, c
     DCVIC_CHECK_ARG((long long)io->H * io->W < (1ll << 30) && (long long)io->Hfull * io->Wfull < (1ll << 30), "conv2d: plane too large");
     DCVIC_CHECK_ARG(!io->res || io->res_batch_stride >= (long long)d->Cout * io->Hfull * io->Wfull, "conv2d: res batch stride too small");
     DCVIC_CHECK_ARG((io->aff_scale == nullptr) == (io->aff_shift == nullptr), "conv2d: affine needs both scale and shift");
+    const int cls = d->cfg;
+    DCVIC_CHECK_ARG(cls >= 0 && cls <= 3, "conv2d: bad cfg %d", cls);
+    init_num_cu();
 
     ConvKArgs K;
     memset(&K, 0, sizeof(K));
-    K.Cin = d->Cin; K.Cout = d->Cout; K.T = d->T; K.stride = d->stride; K.ups = d->upsample;
+    K.Cin = d->Cin; K.Cout = d->Cout; K.T = d->T; K.stride = d->stride;
     K.N = io->N; K.H = io->H; K.W = io->W; K.Hout = io->Hout; K.Wout = io->Wout; K.Hfull = io->Hfull; K.Wfull = io->Wfull;
     K.osy = io->osy; K.osx = io->osx; K.ooy = io->ooy; K.oox = io->oox;
-    K.n_src = io->n_src;
     for (int i = 0; i < DCVIC_MAX_SRC; ++i) {
         if (i < io->n_src) { K.src[i] = io->src[i].ptr; K.srcC[i] = io->src[i].C; K.src_bs[i] = io->src[i].batch_stride; }
         else { K.src[i] = io->src[0].ptr; K.srcC[i] = 1 << 30; K.src_bs[i] = 0; }
     }
-    // sources after the last real one are never selected: make the last real one unbounded
     K.out = io->out; K.out_bs = io->out_batch_stride; K.bias = io->bias; K.act = io->act;
     K.res = io->res; K.res_bs = io->res_batch_stride; K.affs = io->aff_scale; K.afft = io->aff_shift; K.aff_bs = io->aff_batch_stride;
     K.wp = packed;
     int dy_min = 127, dy_max = -128, dx_min = 127, dx_max = -128;
+    // taps must form a regular grid (true for every conv / transposed-conv phase the desc builders emit)
+    {
+        int TX = 1;
+        while (TX < d->T && d->tap_dy[TX] == d->tap_dy[0]) ++TX;
+        DCVIC_CHECK_ARG(d->T % TX == 0, "conv2d: taps are not a grid");
+        const int step = d->T > 1 ? (TX > 1 ? d->tap_dx[1] - d->tap_dx[0] : d->tap_dy[1] - d->tap_dy[0]) : 1;
+        DCVIC_CHECK_ARG(step == 1 || step == -1, "conv2d: tap step %d", step);
+        for (int t = 0; t < d->T; ++t)
+            DCVIC_CHECK_ARG(d->tap_dy[t] == d->tap_dy[0] + (t / TX) * step && d->tap_dx[t] == d->tap_dx[0] + (t % TX) * step,
+                            "conv2d: taps are not a regular grid");
+        K.TX = TX; K.dy0 = d->tap_dy[0]; K.dx0 = d->tap_dx[0]; K.dstep = step;
+    }
     for (int t = 0; t < d->T; ++t) {
-        K.tap[t] = ((int)d->tap_dy[t] & 0xffff) | ((int)d->tap_dx[t] << 16);
         dy_min = min(dy_min, (int)d->tap_dy[t]); dy_max = max(dy_max, (int)d->tap_dy[t]);
         dx_min = min(dx_min, (int)d->tap_dx[t]); dx_max = max(dx_max, (int)d->tap_dx[t]);
     }
     K.dy_min = dy_min; K.dx_min = dx_min;
-    const int cfg = d->cfg;
-    DCVIC_CHECK_ARG(cfg >= 0 && cfg <= 3, "conv2d: bad cfg %d", cfg);
-    const int TC = cfg_TC(cfg), P = cfg_P(cfg);
+    const int TC = cfg_TC(cls);
+    K.n_chunks = n_chunks_of(d);
+    K.n_cotiles = n_cotiles_of(d);
     // tile width: the largest power of two <= 32 that does not exceed the (rounded-up) output width
-    int TWlog = 5;
-    while (TWlog > 2 && (1 << TWlog) > io->Wout && (1 << (TWlog - 1)) >= io->Wout) --TWlog;
-    const int TW = 1 << TWlog, TH = P / TW;
+    const int TWlog = tile_width_log(io->Wout);
+    const int TW = 1 << TWlog;
     K.TWlog = TWlog;
     K.tiles_x = (io->Wout + TW - 1) / TW;
+    // pixel-tile size by the occupancy / tile-efficiency score shared with dcvic_conv_select_class
+    int P = 0;
+    {
+        double best = -1.0;
+        for (int pi = 0; pi < kClassNP[cls]; ++pi) {
+            const double sc = variant_score(cls, kClassP[cls][pi], d->Cout, io->N, io->Hout, io->Wout, d->upsample, g_num_cu);
+            if (sc > best) { best = sc; P = kClassP[cls][pi]; }
+        }
+    }
+    DCVIC_CHECK_ARG(P > 0, "conv2d: no tile variant fits");
+    const int TH = P / TW;
     K.tiles_y = (io->Hout + TH - 1) / TH;
     if (d->upsample) {
         K.PH = TH / 2 + ((dy_max - dy_min + 1) >> 1) + 1;
@@ -395,22 +485,41 @@ extern "C" int dcvic_conv2d_f32(const dcvic_conv_desc* d, const float* packed, c
     }
     K.plane = K.PH * K.PW;
     DCVIC_CHECK_ARG(K.plane <= MAXSLOT * NTHREADS, "conv2d: patch %dx%d exceeds staging slots", K.PH, K.PW);
-    K.n_chunks = n_chunks_of(d);
-    K.n_cotiles = n_cotiles_of(d);
-    // taps per weight stage: keep the slab <= 40 KiB
+    K.nslots = (K.plane + NTHREADS - 1) / NTHREADS;
+    // taps per weight stage: keep the slab <= 40 KiB; several channel chunks per stage when a chunk is small
     int TG = (40 * 1024) / (KC * TC * 4);
     if (TG < 1) TG = 1;
     if (TG > d->T) TG = d->T;
     K.TG = TG;
-    const size_t lds = (size_t)(((KC * K.plane + 3) & ~3) + TG * KC * TC) * sizeof(float);
+    int CPS = 1;
+    if (TG == d->T) {
+        const int per_chunk = (KC * K.plane + d->T * KC * TC) * 4;
+        const int mfma_per_chunk = d->T * (KC / 2) * ((TC / 32) * (P / 32)) / 4;   // per wave
+        while (CPS < 8 && (CPS + 1) * per_chunk <= 48 * 1024 && CPS * mfma_per_chunk < 256) ++CPS;
+        if (CPS > K.n_chunks) CPS = K.n_chunks;
+    }
+    K.CPS = CPS;
+    const int slabs = (TG == d->T) ? CPS * d->T : TG;
+    const size_t lds = (size_t)(((CPS * KC * K.plane + 3) & ~3) + slabs * KC * TC) * sizeof(float);
     DCVIC_CHECK_ARG(lds <= 160 * 1024, "conv2d: LDS %zu too large", lds);
     const long long blocks = (long long)io->N * K.tiles_y * K.tiles_x * K.n_cotiles;
     DCVIC_CHECK_ARG(blocks < (1ll << 31), "conv2d: grid too large");
+    K.nblocks = (int)blocks;
     hipStream_t st = (hipStream_t)stream;
-    switch (cfg) {
-        case 0: return launch_cfg<2, 4, 2, 2>(K, (int)blocks, lds, st);
-        case 1: return launch_cfg<2, 2, 1, 4>(K, (int)blocks, lds, st);
-        case 2: return launch_cfg<1, 2, 1, 4>(K, (int)blocks, lds, st);
-        default: return launch_cfg<3, 2, 1, 4>(K, (int)blocks, lds, st);
+    const bool ups = d->upsample != 0;
+    switch (cls * 1000 + P) {
+        case 0 * 1000 + 256: return launch_variant<2, 4, 2, 2>(K, ups, lds, st);
+        case 0 * 1000 + 128: return launch_variant<2, 2, 2, 2>(K, ups, lds, st);
+        case 0 * 1000 + 64: return launch_variant<2, 1, 2, 2>(K, ups, lds, st);
+        case 1 * 1000 + 256: return launch_variant<2, 2, 1, 4>(K, ups, lds, st);
+        case 1 * 1000 + 128: return launch_variant<1, 2, 2, 2>(K, ups, lds, st);
+        case 1 * 1000 + 64: return launch_variant<1, 1, 2, 2>(K, ups, lds, st);
+        case 2 * 1000 + 256: return launch_variant<1, 2, 1, 4>(K, ups, lds, st);
+        case 2 * 1000 + 128: return launch_variant<1, 1, 1, 4>(K, ups, lds, st);
+        case 3 * 1000 + 256: return launch_variant<3, 2, 1, 4>(K, ups, lds, st);
+        case 3 * 1000 + 128: return launch_variant<3, 1, 1, 4>(K, ups, lds, st);
+        default: break;
     }
+    dcvic_set_error("conv2d: no kernel for class %d P %d", cls, P);
+    return DCVIC_EINVAL;
 }

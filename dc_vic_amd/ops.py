@@ -60,13 +60,31 @@ def kernel_events_stop():
     global _EVENTS
     ev, _EVENTS = _EVENTS, None
     out = {}
-    for cfg, flops, e0, e1 in ev or []:
+    shapes = {}
+    for cfg, flops, e0, e1, shp in ev or []:
         name = CONV_KERNEL_NAMES.get(cfg, f"conv cfg {cfg}")
         d = out.setdefault(name, {"kernel": name, "launches": 0, "flops": 0.0, "time_s": 0.0})
+        t = e0.elapsed_time(e1) * 1e-3
         d["launches"] += 1
         d["flops"] += flops
-        d["time_s"] += e0.elapsed_time(e1) * 1e-3
+        d["time_s"] += t
+        sd = shapes.setdefault((cfg,) + shp, [0, 0.0, 0.0])
+        sd[0] += 1; sd[1] += flops; sd[2] += t
+    global LAST_SHAPE_STATS
+    LAST_SHAPE_STATS = shapes
     return out
+
+
+LAST_SHAPE_STATS = {}
+
+
+def shape_stats_report() -> str:
+    """Per conv shape: launches, total ms, achieved TFLOP/s (diagnostic for kernel tuning)."""
+    rows = sorted(LAST_SHAPE_STATS.items(), key=lambda kv: -kv[1][2])
+    lines = ["cfg Cin Cout T s ups H W N | launches ms TFLOP/s"]
+    for k, (n, fl, t) in rows:
+        lines.append(f"{k} | {n} {t * 1e3:.2f} {fl / t / 1e12:.1f}")
+    return "\n".join(lines)
 
 
 # ------------------------------------------------------------------------------------------- conv
@@ -87,26 +105,27 @@ class ConvPlan:
         w = weight.detach().contiguous()
         if w.dim() == 2:
             w = w.view(w.shape[0], w.shape[1], 1, 1)
-        self.phases: List[Tuple[ConvDesc, Tensor, int, int]] = []
+        self._w = w
+        self.phases: List[list] = []      # [desc, {tile class: packed weights}, py, px]
         if kind == "conv":
             self.Cout, self.Cin, self.KH, self.KW = w.shape
             d = ConvDesc()
             check(lib().dcvic_conv_desc_init(C.byref(d), self.Cin, self.Cout, self.KH, self.KW, stride, pad[0], pad[1],
                                              1 if upsample else 0), "conv_desc_init")
-            self.phases.append((d, self._pack(d, w), 0, 0))
+            self.phases.append([d, {}, 0, 0])
         elif kind == "convT":
             self.Cin, self.Cout, self.KH, self.KW = w.shape
             k = self.KH
             if k == 3:
                 d = ConvDesc()
                 check(lib().dcvic_convT_phase_desc(C.byref(d), self.Cin, self.Cout, 3, 0, 0), "convT_phase_desc")
-                self.phases.append((d, self._pack(d, w), 0, 0))
+                self.phases.append([d, {}, 0, 0])
             else:
                 for py in (0, 1):
                     for px in (0, 1):
                         d = ConvDesc()
                         check(lib().dcvic_convT_phase_desc(C.byref(d), self.Cin, self.Cout, k, py, px), "convT_phase_desc")
-                        self.phases.append((d, self._pack(d, w), py, px))
+                        self.phases.append([d, {}, py, px])
         else:
             raise ValueError(kind)
 
@@ -171,7 +190,8 @@ class ConvPlan:
             if sc.shape[0] not in (1, N):
                 raise ValueError("conv affine batch must be 1 or N")
         st = _stream()
-        for d, packed, py, px in self.phases:
+        for ph in self.phases:
+            d, packs, py, px = ph
             if self.kind == "convT" and self.KH == 5:
                 io.Hout, io.Wout = H, W
                 io.osy = io.osx = 2
@@ -180,12 +200,20 @@ class ConvPlan:
                 io.Hout, io.Wout = Hf, Wf
                 io.osy = io.osx = 1
                 io.ooy = io.oox = 0
+            cls = lib().dcvic_conv_select_class(C.byref(d), N, io.Hout, io.Wout)
+            if cls < 0:
+                check(cls, "conv_select_class")
+            d.cfg = cls
+            packed = packs.get(cls)
+            if packed is None:
+                packed = packs[cls] = self._pack(d, self._w)
             if _EVENTS is not None:
                 e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
                 e0.record()
                 check(lib().dcvic_conv2d_f32(C.byref(d), _p(packed), C.byref(io), st), "conv2d")
                 e1.record()
-                _EVENTS.append((int(d.cfg), 2.0 * N * io.Hout * io.Wout * self.Cout * self.Cin * int(d.T), e0, e1))
+                _EVENTS.append((int(d.cfg), 2.0 * N * io.Hout * io.Wout * self.Cout * self.Cin * int(d.T), e0, e1,
+                                (self.Cin, self.Cout, int(d.T), self.stride, int(self.upsample), H, W, N)))
             else:
                 check(lib().dcvic_conv2d_f32(C.byref(d), _p(packed), C.byref(io), st), "conv2d")
         return out

@@ -115,6 +115,10 @@ int dcvic_conv_desc_init(dcvic_conv_desc* d, int Cin, int Cout, int KH, int KW, 
 /* One output phase (py,px in {0,1}) of ConvTranspose2d(k=5,s=2,p=2,output_padding=1), or the
  * whole ConvTranspose2d(k=3,s=1,p=1) when k==3 (py=px=0). */
 int dcvic_convT_phase_desc(dcvic_conv_desc* d, int Cin, int Cout, int k, int py, int px);
+/* Output-channel tile class (0: 128, 1: 64, 2: 32, 3: 96 channels per workgroup) that fills the chip best
+ * for a launch of N x Hout x Wout outputs; write it to desc.cfg BEFORE packing/launching (packs are per class).
+ * Every class produces bit-identical results (same reduction order). */
+int dcvic_conv_select_class(const dcvic_conv_desc* d, int N, int Hout, int Wout);
 size_t dcvic_conv_packed_bytes(const dcvic_conv_desc* d);
 int dcvic_conv_pack_f32(const dcvic_conv_desc* d, const float* w, float* packed, void* stream);
 int dcvic_conv2d_f32(const dcvic_conv_desc* d, const float* packed, const dcvic_conv_io* io, void* stream);
