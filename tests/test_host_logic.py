@@ -1,0 +1,166 @@
+"""Host-side mirror of the reference's interface: config loader, registries, wire format, state-dict layout,
+synthetic weights.  CPU only (no kernel is launched)."""
+import json
+import os
+import textwrap
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_wire_format_matches_reference_bytes():
+    from dc_vic_amd.codec_utils import HeaderHandler, pack_byte_strings, unpack_byte_strings
+    W = json.load(open(os.path.join(ROOT, "tests", "golden", "wire_format.json")))
+    hh = HeaderHandler()
+    assert hh.encode((512, 768), torch.tensor([37.9, -3.0]), 0).hex() == W["hdr_512_768_37p9_q0"] == "000200032500"
+    assert hh.encode((256, 256), torch.tensor([-3.99]), 4).hex() == W["hdr_256_256_3p99_q4"] == "000100010304"
+    assert hh.encode((1, 65535), 0.2, 2).hex() == W["hdr_1_65535_0_q2"]
+    strings = [bytes.fromhex(W["hdr_512_768_37p9_q0"]), b"\x01\x02\x03", b"\xaa" * 5]
+    assert pack_byte_strings(strings).hex() == W["container"]
+    assert [s.hex() for s in unpack_byte_strings(bytes.fromhex(W["container"]))] == W["container_loaded"]
+    assert pack_byte_strings([b"", b"\x07"]).hex() == W["container_empty_first"]
+    d = hh.decode(bytes.fromhex(W["hdr_512_768_37p9_q0"]))
+    assert list(d["img_size"]) == W["hdr_decode_512_768"]["img_size"] and d["max_sample"] == 37 and d["quality_ind"] == 0
+    assert hh.encode((64, 64), 300.7, 1)[4] == 300 % 256          # NumPy-1.24 wrap of max_sample
+    with pytest.raises(ValueError):
+        hh.encode((70000, 4), 0.0, 0)
+    with pytest.raises(ValueError):
+        unpack_byte_strings(b"\x05\x00\x00\x00abc")
+    with pytest.raises(AssertionError):
+        hh.encode((1.5, 2), 0.0, 0)
+
+
+def test_config_base_delete_merge(tmp_path):
+    from dc_vic_amd.options import BaseConfig
+    (tmp_path / "b1.yaml").write_text(textwrap.dedent("""
+        model: {type: M, a: 1, nested: {x: 1, y: 2}}
+        subnet: {enc: {type: E, ch: 3}}
+    """))
+    (tmp_path / "b2.yaml").write_text("other: {k: v}\n")
+    (tmp_path / "dup.yaml").write_text("model: {type: Z}\n")
+    (tmp_path / "child.yaml").write_text(textwrap.dedent("""
+        _base_: [./b1.yaml, ./b2.yaml]
+        model: {a: 5, nested: {y: 3}}
+        subnet: {enc: {_delete_: true, type: F}}
+    """))
+    c = BaseConfig.fromfile(str(tmp_path / "child.yaml"), {"device": "cpu", "quality": 2})
+    assert c.model.type == "M" and c.model.a == 5 and c.model.nested.x == 1 and c.model.nested.y == 3
+    assert dict(c.subnet.enc) == {"type": "F"}            # _delete_ replaced the base dict
+    assert c.other.k == "v" and c.device == "cpu" and c.quality == 2
+    with pytest.raises(AttributeError):
+        c.model.missing
+    (tmp_path / "bad.yaml").write_text("_base_: [./b1.yaml, ./dup.yaml]\n")
+    with pytest.raises(KeyError):
+        BaseConfig.fromfile(str(tmp_path / "bad.yaml"))
+    (tmp_path / "bad2.yaml").write_text("_base_: ./b1.yaml\nmodel: {a: {z: 1}}\n")
+    with pytest.raises(TypeError):
+        BaseConfig.fromfile(str(tmp_path / "bad2.yaml"))
+    with pytest.raises(IOError):
+        BaseConfig._file2dict_yaml(__file__)
+
+
+def test_registry_contract():
+    from dc_vic_amd import registry as R
+    import dc_vic_amd.comp_model  # noqa: F401  (registers everything)
+    for name in ["HyperpriorCharmDualCondVicModel", "HyperpriorDualCondVicModel", "HyperpriorVicModel"]:
+        assert name in R.MODEL_REGISTRY
+    assert "ElicDualBetaFtVqScEncoder" in R.ENCODER_REGISTRY and "ElicDualBetaFtFeatFusionDecoder" in R.DECODER_REGISTRY
+    assert "Minnen20HyperEncoder" in R.HYPERENCODER_REGISTRY and "Minnen20HyperDecoder" in R.HYPERDECODER_REGISTRY
+    assert "Minnen20CharmContextModel" in R.CONTEXTMODEL_REGISTRY
+    assert "SteEntropyBottleneck" in R.ENTROPYMODEL_REGISTRY and "SteGaussianMeanScaleConditional" in R.ENTROPYMODEL_REGISTRY
+    assert "DualBlockSwinVqEstimator" in R.VQ_ESTIMATOR_REGISTRY and "VqDecFusionModule" in R.VQ_FUSION_REGISTRY
+    with pytest.raises(KeyError):
+        R.ENCODER_REGISTRY.get("Nope")
+    reg = R.Registry("t")
+
+    @reg.register()
+    class A:  # noqa
+        pass
+    assert reg.get("A") is A
+    with pytest.raises(AssertionError):
+        reg.register()(A)
+
+
+@pytest.fixture(scope="module")
+def cpu_model():
+    from dc_vic_amd import BaseConfig, build_comp_model
+    opt = BaseConfig.fromfile(os.path.join(ROOT, "config", "dc_vic_synthetic.yaml"), {"device": "cpu"})
+    return build_comp_model(opt)
+
+
+def test_state_dict_layout_matches_reference(cpu_model, manifest):
+    """Every tensor of the reference's importable sub-modules exists under the same key with the same shape
+    (so reference checkpoints load by key); CompressAI-side keys follow SURVEY App-B/App-E."""
+    sd = cpu_model.state_dict()
+    for k, (shape, dtype) in manifest.items():
+        assert k in sd, k
+        assert list(sd[k].shape) == shape, k
+    extra = [k for k in sd if k not in manifest and not k.startswith(("context_model.", "entropy_model_z.", "entropy_model_y."))]
+    assert extra == []
+    for k in ["entropy_model_z._matrix0", "entropy_model_z._bias4", "entropy_model_z._factor3", "entropy_model_z.quantiles",
+              "entropy_model_z._quantized_cdf", "entropy_model_z._offset", "entropy_model_z._cdf_length",
+              "entropy_model_y.scale_table", "entropy_model_y._quantized_cdf",
+              "context_model.mean_slice_transforms.0.model.0.weight", "context_model.lrp_slice_transforms.5.model.4.bias"]:
+        assert k in sd, k
+    assert tuple(sd["context_model.lrp_slice_transforms.5.model.0.weight"].shape) == (224, 128 + 4 * 32 + 32, 5, 5)
+    assert tuple(sd["encoder.projection.weight"].shape) == (192, 452, 3, 3)
+
+
+def test_load_learned_weight_roundtrip(cpu_model, tmp_path, synth_sd):
+    """Checkpoint file format of model_saver.py:39-46 ({'iter', 'comp_model': state_dict}), 'module.' prefix
+    stripped, unknown keys ignored, CDF buffers resized from the checkpoint (base_model.py:88-130)."""
+    ck = {"iter": 7, "comp_model": {("module." + k): v for k, v in synth_sd.items()}}
+    ck["comp_model"]["module.not_a_key"] = torch.zeros(3)
+    ck["comp_model"]["module.entropy_model_y._quantized_cdf"] = torch.zeros((64, 9), dtype=torch.int32)
+    ck["comp_model"]["module.entropy_model_y._cdf_length"] = torch.full((64,), 9, dtype=torch.int32)
+    ck["comp_model"]["module.entropy_model_y._offset"] = torch.zeros((64,), dtype=torch.int32)
+    path = str(tmp_path / "ck.pth.tar")
+    torch.save(ck, path)
+    cpu_model.load_learned_weight(path)
+    sd = cpu_model.state_dict()
+    assert torch.equal(sd["vq_model.encoder.conv_in.weight"], synth_sd["vq_model.encoder.conv_in.weight"])
+    assert torch.equal(sd["context_model.scale_slice_transforms.3.model.2.bias"], synth_sd["context_model.scale_slice_transforms.3.model.2.bias"])
+    assert tuple(sd["entropy_model_y._quantized_cdf"].shape) == (64, 9)
+    assert sd["entropy_model_z._quantized_cdf"].numel() > 0            # update(force=False) ran
+
+
+def test_no_gpu_means_loud_failure(cpu_model):
+    """There is no CPU fallback: running the path without a HIP device raises instead of silently computing."""
+    x = torch.zeros(1, 3, 64, 64)
+    with pytest.raises(Exception):
+        cpu_model.run_model(x, is_train=False, beta_rate=2.29, beta_vq=3.0)
+    with pytest.raises(NotImplementedError):
+        cpu_model.run_model(x, is_train=True, beta_rate=2.29, beta_vq=3.0)
+    with pytest.raises(ValueError):
+        cpu_model.run_model(x, is_train=False)
+    with pytest.raises(AssertionError):
+        cpu_model.compress(torch.zeros(2, 3, 64, 64), 0)
+
+
+def test_synth_weights_deterministic(manifest):
+    from dc_vic_amd.synth import synth_tensor, full_synth_state_dict
+    a = synth_tensor("vq_model.encoder.conv_in.weight", (128, 3, 3, 3))
+    b = synth_tensor("vq_model.encoder.conv_in.weight", (128, 3, 3, 3))
+    assert torch.equal(a, b)
+    cb = synth_tensor("vq_model.quantize.embedding.weight", (256, 4))
+    assert float(cb.abs().max()) <= 1 / 256                      # taming quantize.py:229-230
+    sd = full_synth_state_dict(1234)
+    assert len(sd) > 1000 and all(v.dtype == torch.float32 for v in sd.values())
+
+
+def test_png_loader_matches_totensor_normalize(tmp_path):
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("dcvic_cli", os.path.join(ROOT, "scripts", "compress.py"))
+    cli = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(cli)
+    from PIL import Image
+    rng = np.random.default_rng(0)
+    img = rng.integers(0, 256, size=(5, 7, 3), dtype=np.uint8)
+    p = str(tmp_path / "a.png")
+    Image.fromarray(img).save(p)
+    x = cli.load_png(p)
+    ref = (torch.from_numpy(img).permute(2, 0, 1).float() / 255.0 - 0.5) / 0.5
+    assert x.shape == (1, 3, 5, 7) and torch.equal(x[0], ref)

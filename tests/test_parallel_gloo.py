@@ -1,0 +1,48 @@
+"""N>1 path on CPU: image sharding + the all_gather of the per-image rate table, world_size 2 over gloo."""
+import os
+import socket
+
+import numpy as np
+import torch
+import torch.multiprocessing as mp
+
+from dc_vic_amd.parallel import gather_rate_table, shard_indices
+
+
+def test_shard_indices_partition_and_balance():
+    costs = [512 * 768] * 5 + [2048 * 1344] * 2 + [64 * 64] * 9
+    for world in (1, 2, 3, 8):
+        parts = [shard_indices(len(costs), r, world, costs) for r in range(world)]
+        flat = sorted(i for p in parts for i in p)
+        assert flat == list(range(len(costs)))                       # every image exactly once
+        loads = [sum(costs[i] for i in p) for p in parts]
+        assert max(loads) - min(loads) <= max(costs)                  # LPT bound
+    assert shard_indices(10, 1, 4) == [1, 5, 9]                        # uniform cost -> round robin
+    assert shard_indices(3, 0, 1) == [0, 1, 2]
+
+
+def _worker(rank, world, port, out_dir):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    n_items = 7
+    mine = shard_indices(n_items, rank, world, [10, 1, 1, 1, 9, 1, 1])
+    table = np.array([[i, 100.0 + i, 0.5 * i] for i in mine], dtype=np.float64).reshape(-1, 3)
+    full = gather_rate_table(table, dist)
+    np.save(os.path.join(out_dir, f"r{rank}.npy"), full)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_gather_rate_table_world2(tmp_path):
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    a, b = np.load(tmp_path / "r0.npy"), np.load(tmp_path / "r1.npy")
+    assert np.array_equal(a, b)                                        # every rank sees the same table
+    assert sorted(a[:, 0].tolist()) == list(range(7))                  # ragged shards (4 + 3 rows) gathered without loss
+    a = a[np.argsort(a[:, 0])]
+    assert np.allclose(a[:, 1], 100.0 + np.arange(7)) and np.allclose(a[:, 2], 0.5 * np.arange(7))
+    # single process: identity
+    t = np.arange(6, dtype=np.float64).reshape(3, 2)
+    assert np.array_equal(gather_rate_table(t, None), t)
