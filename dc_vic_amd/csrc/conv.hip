@@ -20,38 +20,7 @@
 // The fp32 MFMA is a k-ordered fmaf chain, so the reduction order of an output element is
 // (chunk asc, tap asc, channel asc) for EVERY variant, grid and batch size: results are deterministic,
 // batch-invariant and identical across variants (needed for encoder/decoder agreement).
-#include "common.h"
-
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-
-#define KC 8
-#define MAXSLOT 6
-#define NTHREADS 256
-#define NXCD 8
-
-struct ConvKArgs {
-    int Cin, Cout, T, stride;
-    int N, H, W, Hout, Wout, Hfull, Wfull, osy, osx, ooy, oox;
-    const float* src[DCVIC_MAX_SRC];
-    int srcC[DCVIC_MAX_SRC];
-    long long src_bs[DCVIC_MAX_SRC];
-    float* out;
-    long long out_bs;
-    const float* bias;
-    int act;
-    const float* res;
-    long long res_bs;
-    const float* affs;
-    const float* afft;
-    long long aff_bs;
-    const float* wp;
-    int TX, dy0, dx0, dstep;  // taps form a grid: t = iy*TX + ix, dy = dy0 + iy*dstep, dx = dx0 + ix*dstep
-    int nslots;               // ceil(plane / NTHREADS)
-    int TWlog, tiles_x, tiles_y;
-    int PH, PW, plane, dy_min, dx_min;
-    int TG, CPS, n_chunks, n_cotiles;
-    int nblocks;
-};
+#include "conv_common.h"
 
 template <int MT, int NT, int WM, int WN, bool UPS>
 __global__ __launch_bounds__(NTHREADS, (MT * NT >= 8) ? 2 : ((MT * NT >= 4) ? 3 : 4)) void conv_mfma_kernel(const ConvKArgs K) {
@@ -162,37 +131,48 @@ __global__ __launch_bounds__(NTHREADS, (MT * NT >= 8) ? 2 : ((MT * NT >= 4) ? 3 
                 }
             }
             __syncthreads();
+            // Reduction order inside an 8-channel chunk: (tap, channel) for most layers; the 3x3/stride-1 family
+            // uses (4-channel half, tap, channel) -- the order of conv3x3.hip's 4-channel pipeline stages -- so that
+            // both kernels give bit-identical results (K.halves == 2).
+            const int n_outer = K.halves, n_inner = 3 - K.halves;      // (1, 2) or (2, 1)
             for (int cs = 0; cs < ncs; ++cs) {
                 const float* xb0 = Xs + cs * (KC * K.plane);
-                int tiy = tg / K.TX, tix = tg - tiy * K.TX;
-                for (int tt = 0; tt < ntap; ++tt) {
-                    const int dy = K.dy0 + tiy * K.dstep, dx = K.dx0 + tix * K.dstep;
-                    if (++tix == K.TX) { tix = 0; ++tiy; }
-                    int boff[NT];
-                    const float* xb;
-                    if (UPS) {
-                        xb = xb0;
-#pragma unroll
-                        for (int nt = 0; nt < NT; ++nt)
-                            boff[nt] = (((oy0 + pty[nt] + dy) >> 1) - iy0) * K.PW + (((ox0 + ptx[nt] + dx) >> 1) - ix0) + lane_k * K.plane;
-                    } else {
-                        xb = xb0 + (dy - K.dy_min) * K.PW + (dx - K.dx_min);   // uniform tap offset
-#pragma unroll
-                        for (int nt = 0; nt < NT; ++nt) boff[nt] = bbase[nt];
-                    }
-                    const float* As = Ws + ((cs * ntap + tt) * KC + lane_k) * TC + wm * (MT * 32) + lane_j;
-#pragma unroll
-                    for (int ks = 0; ks < KC / 2; ++ks) {
-                        float a[MT], bb[NT];
-#pragma unroll
-                        for (int mt = 0; mt < MT; ++mt) a[mt] = As[(2 * ks) * TC + mt * 32];
-#pragma unroll
-                        for (int nt = 0; nt < NT; ++nt) bb[nt] = xb[boff[nt] + (2 * ks) * K.plane];
-#pragma unroll
-                        for (int mt = 0; mt < MT; ++mt)
+                for (int po = 0; po < n_outer; ++po) {
+                    int tiy = tg / K.TX, tix = tg - tiy * K.TX;
+                    for (int tt = 0; tt < ntap; ++tt) {
+                        const int dy = K.dy0 + tiy * K.dstep, dx = K.dx0 + tix * K.dstep;
+                        if (++tix == K.TX) { tix = 0; ++tiy; }
+                        int boff[NT];
+                        const float* xb;
+                        if (UPS) {
+                            xb = xb0;
 #pragma unroll
                             for (int nt = 0; nt < NT; ++nt)
-                                acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mt], bb[nt], acc[mt][nt], 0, 0, 0);
+                                boff[nt] = (((oy0 + pty[nt] + dy) >> 1) - iy0) * K.PW + (((ox0 + ptx[nt] + dx) >> 1) - ix0) + lane_k * K.plane;
+                        } else {
+                            xb = xb0 + (dy - K.dy_min) * K.PW + (dx - K.dx_min);   // uniform tap offset
+#pragma unroll
+                            for (int nt = 0; nt < NT; ++nt) boff[nt] = bbase[nt];
+                        }
+                        const float* As0 = Ws + ((cs * ntap + tt) * KC + lane_k) * TC + wm * (MT * 32) + lane_j;
+                        for (int pi = 0; pi < n_inner; ++pi) {
+                            const int kb = 4 * (po + pi);                       // first channel of this half
+                            const float* As = As0 + kb * TC;
+                            const float* xk = xb + kb * K.plane;
+#pragma unroll
+                            for (int ks = 0; ks < KC / 4; ++ks) {
+                                float a[MT], bb[NT];
+#pragma unroll
+                                for (int mt = 0; mt < MT; ++mt) a[mt] = As[(2 * ks) * TC + mt * 32];
+#pragma unroll
+                                for (int nt = 0; nt < NT; ++nt) bb[nt] = xk[boff[nt] + (2 * ks) * K.plane];
+#pragma unroll
+                                for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                                    for (int nt = 0; nt < NT; ++nt)
+                                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mt], bb[nt], acc[mt][nt], 0, 0, 0);
+                            }
+                        }
                     }
                 }
             }
@@ -259,6 +239,8 @@ static const int kClassP[4][3] = {{256, 128, 64}, {256, 128, 64}, {256, 128, 0},
 static inline int cfg_TC(int c) { return kClassTC[c]; }
 
 static int g_num_cu = 0;
+static thread_local int g_last_variant = -1;   // 9000: conv3x3_dma_kernel; else cls*1000 + P (+1 when UPS)
+static int g_use_dma = 1;   // DCVIC_CONV_DMA=0 forces the generic kernel (A/B comparisons, debugging)
 
 static int tile_width_log(int Wout) {
     int TWlog = 5;
@@ -385,11 +367,15 @@ static int launch_variant(const ConvKArgs& K, bool ups, size_t lds, hipStream_t 
 
 static void init_num_cu() {
     if (g_num_cu == 0) {
+        const char* e = getenv("DCVIC_CONV_DMA");
+        if (e && e[0] == '0') g_use_dma = 0;
         int dev = 0, cu = 0;
         if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cu > 0) g_num_cu = cu;
         else g_num_cu = 256;
     }
 }
+
+extern "C" int dcvic_conv_last_variant(void) { return g_last_variant; }
 
 extern "C" int dcvic_conv_select_class(const dcvic_conv_desc* d, int N, int Hout, int Wout) {
     if (!d || N <= 0 || Hout <= 0 || Wout <= 0) return DCVIC_EINVAL;
@@ -456,6 +442,13 @@ extern "C" int dcvic_conv2d_f32(const dcvic_conv_desc* d, const float* packed, c
         dx_min = min(dx_min, (int)d->tap_dx[t]); dx_max = max(dx_max, (int)d->tap_dx[t]);
     }
     K.dy_min = dy_min; K.dx_min = dx_min;
+    // layer-only predicate (never N / size / tile class): the 3x3 stride-1 pad-1 family shares conv3x3.hip's order
+    {
+        bool fam = d->T == 9 && K.TX == 3 && K.dstep == 1 && K.dy0 == -1 && K.dx0 == -1 && d->stride == 1 && !d->upsample &&
+                   (d->Cin % KC) == 0;
+        for (int i = 0; i < io->n_src; ++i) fam = fam && (io->src[i].C % KC) == 0;
+        K.halves = fam ? 2 : 1;
+    }
     const int TC = cfg_TC(cls);
     K.n_chunks = n_chunks_of(d);
     K.n_cotiles = n_cotiles_of(d);
@@ -507,6 +500,11 @@ extern "C" int dcvic_conv2d_f32(const dcvic_conv_desc* d, const float* packed, c
     K.nblocks = (int)blocks;
     hipStream_t st = (hipStream_t)stream;
     const bool ups = d->upsample != 0;
+    if (P == 256 && g_use_dma) {
+        const int rc = dcvic_try_conv3x3_dma(K, io->n_src, ups, cls, st);
+        if (rc <= 0) { g_last_variant = 9000; return rc; }
+    }
+    g_last_variant = cls * 1000 + P + (ups ? 1 : 0);
     switch (cls * 1000 + P) {
         case 0 * 1000 + 256: return launch_variant<2, 4, 2, 2>(K, ups, lds, st);
         case 0 * 1000 + 128: return launch_variant<2, 2, 2, 2>(K, ups, lds, st);

@@ -1,0 +1,194 @@
+// conv3x3.hip -- the hot 3x3 / stride-1 / pad-1 convolution (90 % of the path's flops) with the LDS
+// double-buffered by LDS-DMA (`global_load_lds`), gfx950.
+//
+// Same GEMM view, packed-weight layout, reduction order and epilogue as conv.hip (results are
+// bit-identical to the generic kernel); what changes is the pipeline:
+//   * 512 threads = 8 waves per workgroup on a 128 (out channels) x 256 (8 rows x 32 pixels) tile,
+//     waves as 2 (channel halves) x 4 (row pairs), each wave 2x2 MFMA 32x32x2 accumulators, two waves
+//     per SIMD so one wave's LDS latency hides behind the other's MFMAs;
+//   * a pipeline stage is 4 input channels: the input patch (4 ch x 10 x 34, zero padded via a zero
+//     word for out-of-image lanes) and the weight rows (9 taps x 4 x 128) of stage i+1 are written
+//     straight into the other LDS buffer by `global_load_lds_dword / _dwordx4` (no VGPR staging, no
+//     ds_write) while stage i is computed; one barrier per stage (hipcc drains the DMA with vmcnt(0)
+//     in front of it); 48 KiB of LDS per workgroup so that 2-3 workgroups share a CU and one
+//     workgroup's barrier / DMA issue hides behind the others' MFMAs;
+//   * tap and channel offsets are compile-time immediates of ds_read_b32 -- no address VALU in the loop.
+// LDS: 2 x (1536 + 4608) floats = 48 KiB per workgroup.
+#include "conv_common.h"
+
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+
+__device__ float dcvic_zero_word[16];   // zero-initialised: source of padded lanes
+
+#define D_TC 128
+#define D_TW 32
+#define D_TH 8
+#define D_PW 34
+#define D_PLANE 340
+#define D_SKC 4                           /* channels per pipeline stage (half a packed chunk) */
+#define D_THREADS 512
+#define D_SLOTS 3                         /* ceil(D_SKC * D_PLANE / D_THREADS) */
+#define D_XS (D_SLOTS * D_THREADS)        /* 1536 floats (1360 used) */
+#define D_WS (9 * D_SKC * D_TC)           /* 4608 floats */
+#define D_BUF (D_XS + D_WS)
+#define D_CHUNK_W (9 * KC * D_TC)         /* floats of one packed 8-channel chunk */
+
+__global__ __launch_bounds__(D_THREADS, 2) void conv3x3_dma_kernel(const ConvKArgs K) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;           // 0..7
+    const int wm = wave >> 2, wn = wave & 3;
+    const int lane_k = lane >> 5, lane_j = lane & 31;
+
+    int b;
+    {
+        const int orig = blockIdx.x, nb = K.nblocks;
+        const int q = nb / NXCD, r = nb % NXCD, x = orig % NXCD;
+        b = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + orig / NXCD;
+    }
+    const int cotile = b % K.n_cotiles; b /= K.n_cotiles;
+    const int tile_x = b % K.tiles_x; b /= K.tiles_x;
+    const int tile_y = b % K.tiles_y; b /= K.tiles_y;
+    const int n = b;
+    const int oy0 = tile_y * D_TH, ox0 = tile_x * D_TW;
+    const int iy0 = oy0 - 1, ix0 = ox0 - 1;
+    const long long HW = (long long)K.H * K.W;
+
+    // per-slot source offsets of the patch elements this thread moves (identical for every chunk)
+    int poff[D_SLOTS];
+#pragma unroll
+    for (int s = 0; s < D_SLOTS; ++s) {
+        const int e = tid + s * D_THREADS;
+        int o = -1;
+        if (e < D_SKC * D_PLANE) {
+            const int k = e / D_PLANE, r = e - k * D_PLANE;
+            const int py = r / D_PW, px = r - py * D_PW;
+            const int iy = iy0 + py, ix = ix0 + px;
+            if (iy >= 0 && iy < K.H && ix >= 0 && ix < K.W) o = (int)(k * HW) + iy * K.W + ix;
+        }
+        poff[s] = o;
+    }
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const float* wbase = K.wp + (long long)cotile * K.n_chunks * (long long)D_CHUNK_W;
+    const int n_stages = K.n_chunks * (KC / D_SKC);
+
+    auto issue = [&](int stage, int buf) {
+        int c = stage * D_SKC, si = 0;
+        if (c >= K.srcC[0]) { c -= K.srcC[0]; si = 1; if (c >= K.srcC[1]) { c -= K.srcC[1]; si = 2; } }
+        const float* base = K.src[si] + (long long)n * K.src_bs[si] + (long long)c * HW;
+        float* xb = smem + buf * D_BUF;
+        float* wb = xb + D_XS;
+#pragma unroll
+        for (int s = 0; s < D_SLOTS; ++s) {
+            const float* gp = poff[s] >= 0 ? base + poff[s] : dcvic_zero_word;
+            __builtin_amdgcn_global_load_lds(gp, (lds_ptr_t)(xb + wave * 64 + s * D_THREADS), 4, 0, 0);
+        }
+        // weight rows of this stage: for each tap, D_SKC x 128 floats = 128 float4 at (tap*8 + half*4)*128 of the chunk
+        const int chunk = stage / (KC / D_SKC), half = stage % (KC / D_SKC);
+        const float4* w4 = reinterpret_cast<const float4*>(wbase + (long long)chunk * D_CHUNK_W) + half * (D_SKC * D_TC / 4);
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const int v = tid + j * D_THREADS;           // 9 * 128 = 1152 float4 = 2.25 x 512
+            if (j < 2 || wave < 2) {
+                const int t = v >> 7, i = v & 127;
+                __builtin_amdgcn_global_load_lds(w4 + t * (KC * D_TC / 4) + i, (lds_ptr_t)(wb + (wave * 64 + j * D_THREADS) * 4), 16, 0, 0);
+            }
+        }
+    };
+
+    issue(0, 0);
+    __syncthreads();
+
+    const int xlane = lane_k * D_PLANE + (wn * 2) * D_PW + lane_j;
+    const int alane = lane_k * D_TC + wm * 64 + lane_j;
+    for (int stage = 0; stage < n_stages; ++stage) {
+        const int buf = stage & 1;
+        if (stage + 1 < n_stages) issue(stage + 1, buf ^ 1);
+        const float* xb = smem + buf * D_BUF + xlane;
+        const float* wb = smem + buf * D_BUF + D_XS + alane;
+        // 18 steps (9 taps x 2 channel pairs), software pipelined: the fragments of step s+1 are in flight
+        // while the four MFMAs of step s issue
+        float a_cur[2], b_cur[2], a_nxt[2], b_nxt[2];
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) a_cur[mt] = wb[mt * 32];
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) b_cur[nt] = xb[nt * D_PW];
+#pragma unroll
+        for (int step = 0; step < 9 * D_SKC / 2; ++step) {
+            if (step + 1 < 9 * D_SKC / 2) {
+                const int t = (step + 1) / (D_SKC / 2), ks = (step + 1) % (D_SKC / 2);
+                const int ky = t / 3, kx = t - 3 * ky;
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt) a_nxt[mt] = wb[(t * D_SKC + 2 * ks) * D_TC + mt * 32];
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt) b_nxt[nt] = xb[(2 * ks) * D_PLANE + (nt + ky) * D_PW + kx];
+            }
+            __builtin_amdgcn_sched_barrier(0);   // keep the prefetch of step s+1 ahead of the MFMAs of step s
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt)
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[mt], b_cur[nt], acc[mt][nt], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < 2; ++i) { a_cur[i] = a_nxt[i]; b_cur[i] = b_nxt[i]; }
+        }
+        __syncthreads();
+    }
+
+    // ---- epilogue: bias -> act -> (+res) -> (affine) -> store  (same order as conv.hip)
+    const long long HWo = (long long)K.Hfull * K.Wfull;
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+        const int oy = oy0 + wn * 2 + nt, ox = ox0 + lane_j;
+        if (oy >= K.Hout || ox >= K.Wout) continue;
+        const long long pix = (long long)(oy * K.osy + K.ooy) * K.Wfull + (ox * K.osx + K.oox);
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = cotile * D_TC + (wm * 2 + mt) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lane_k;
+                if (co >= K.Cout) continue;
+                float v = acc[mt][nt][r];
+                if (K.bias) v += K.bias[co];
+                v = dcvic_act(v, K.act);
+                if (K.res) v += K.res[(long long)n * K.res_bs + (long long)co * HWo + pix];
+                if (K.affs) {
+                    const long long ai = (long long)n * K.aff_bs + co;
+                    v = v * (1.f + K.affs[ai]) + K.afft[ai];
+                }
+                K.out[(long long)n * K.out_bs + (long long)co * HWo + pix] = v;
+            }
+        }
+    }
+}
+
+int dcvic_try_conv3x3_dma(const ConvKArgs& Kin, int n_src, bool upsample, int cls, hipStream_t st) {
+    const ConvKArgs& K = Kin;
+    if (K.halves != 2 || upsample || cls != 0 || K.TWlog != 5) return 1;   // halves == 2 <=> 3x3/s1/p1 family, channels % 8 == 0
+    if ((long long)K.H * K.W * KC >= (1ll << 31)) return 1;
+    ConvKArgs A = K;
+    A.tiles_y = (K.Hout + D_TH - 1) / D_TH;
+    A.tiles_x = (K.Wout + D_TW - 1) / D_TW;
+    const long long blocks = (long long)K.N * A.tiles_y * A.tiles_x * K.n_cotiles;
+    if (blocks >= (1ll << 31)) return 1;
+    A.nblocks = (int)blocks;
+    static bool attr_set = false;
+    const size_t lds = (size_t)2 * D_BUF * sizeof(float);
+    if (!attr_set) {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_dma_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set = true;
+    }
+    conv3x3_dma_kernel<<<A.nblocks, D_THREADS, lds, st>>>(A);
+    DCVIC_CHECK_LAUNCH("conv3x3_dma");
+    return DCVIC_OK;
+}

@@ -46,8 +46,17 @@ def new(N, Cc, H, W, like: Tensor) -> Tensor:
 # Per-launch HIP events on the stream the conv kernels run on (torch's current stream), used by
 # bench.py to report the dominant kernel's achieved TFLOP/s inside the timed region.
 _EVENTS = None
-CONV_KERNEL_NAMES = {0: "conv_mfma_kernel<2,4,2,2>", 1: "conv_mfma_kernel<2,2,1,4>", 2: "conv_mfma_kernel<1,2,1,4>",
-                     3: "conv_mfma_kernel<3,2,1,4>"}
+_VARIANT_TILES = {(0, 256): "2, 4, 2, 2", (0, 128): "2, 2, 2, 2", (0, 64): "2, 1, 2, 2", (1, 256): "2, 2, 1, 4", (1, 128): "1, 2, 2, 2",
+                  (1, 64): "1, 1, 2, 2", (2, 256): "1, 2, 1, 4", (2, 128): "1, 1, 1, 4", (3, 256): "3, 2, 1, 4", (3, 128): "3, 1, 1, 4"}
+
+
+def conv_kernel_name(variant: int) -> str:
+    """Kernel name as rocprofv3 prints it, from dcvic_conv_last_variant()."""
+    if variant == 9000:
+        return "conv3x3_dma_kernel(ConvKArgs)"
+    cls, rest = divmod(variant, 1000)
+    P, ups = rest - (rest & 1), rest & 1
+    return f"void conv_mfma_kernel<{_VARIANT_TILES.get((cls, P), '?')}, {'true' if ups else 'false'}>(ConvKArgs)"
 
 
 def kernel_events_start() -> None:
@@ -62,7 +71,7 @@ def kernel_events_stop():
     out = {}
     shapes = {}
     for cfg, flops, e0, e1, shp in ev or []:
-        name = CONV_KERNEL_NAMES.get(cfg, f"conv cfg {cfg}")
+        name = conv_kernel_name(cfg)
         d = out.setdefault(name, {"kernel": name, "launches": 0, "flops": 0.0, "time_s": 0.0})
         t = e0.elapsed_time(e1) * 1e-3
         d["launches"] += 1
@@ -212,7 +221,7 @@ class ConvPlan:
                 e0.record()
                 check(lib().dcvic_conv2d_f32(C.byref(d), _p(packed), C.byref(io), st), "conv2d")
                 e1.record()
-                _EVENTS.append((int(d.cfg), 2.0 * N * io.Hout * io.Wout * self.Cout * self.Cin * int(d.T), e0, e1,
+                _EVENTS.append((int(lib().dcvic_conv_last_variant()), 2.0 * N * io.Hout * io.Wout * self.Cout * self.Cin * int(d.T), e0, e1,
                                 (self.Cin, self.Cout, int(d.T), self.stride, int(self.upsample), H, W, N)))
             else:
                 check(lib().dcvic_conv2d_f32(C.byref(d), _p(packed), C.byref(io), st), "conv2d")

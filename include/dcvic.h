@@ -68,8 +68,10 @@ int dcvic_device_info(int* n_cu, int* lds_bytes);
  * with IN = the channel concatenation of up to 3 source views (zero outside the image), or its
  * nearest x2 upsampling when `upsample` is set.  A transposed convolution is issued as one
  * launch per output phase with osy=osx=2 (see dcvic_convT_phase_desc).
- * Reduction order per output element: input-channel chunks of 8 ascending; inside a chunk taps
- * t ascending; inside a tap the 8 channels ascending; one fp32 FMA per term (MFMA 32x32x2 f32).
+ * Reduction order per output element (a function of the LAYER only, never of N, sizes or the tile variant):
+ * input-channel chunks of 8 ascending; inside a chunk taps t ascending; inside a tap the 8 channels ascending --
+ * except the 3x3/stride-1/pad-1 family with Cin % 8 == 0, which runs (4-channel half, tap, channel) inside a chunk
+ * (the pipeline-stage order of the LDS-DMA kernel); one fp32 FMA per term (MFMA 32x32x2 f32).
  */
 typedef struct {
     int Cin, Cout;
@@ -119,6 +121,9 @@ int dcvic_convT_phase_desc(dcvic_conv_desc* d, int Cin, int Cout, int k, int py,
  * for a launch of N x Hout x Wout outputs; write it to desc.cfg BEFORE packing/launching (packs are per class).
  * Every class produces bit-identical results (same reduction order). */
 int dcvic_conv_select_class(const dcvic_conv_desc* d, int N, int Hout, int Wout);
+/* Which kernel the calling thread's last dcvic_conv2d_f32 launched (profiling aid):
+ * 9000 = conv3x3_dma_kernel, otherwise class*1000 + pixels-per-tile (+1 for the upsample loader). */
+int dcvic_conv_last_variant(void);
 size_t dcvic_conv_packed_bytes(const dcvic_conv_desc* d);
 int dcvic_conv_pack_f32(const dcvic_conv_desc* d, const float* w, float* packed, void* stream);
 int dcvic_conv2d_f32(const dcvic_conv_desc* d, const float* packed, const dcvic_conv_io* io, void* stream);

@@ -329,3 +329,32 @@ def test_eb_rate(dev, synth_sd):
     assert torch.equal(sym.cpu(), eb.symbols(z))
     close(lik, lik_ref, rtol=2e-4, atol=3e-7)
     close(bits, -(torch.log(lik_ref).reshape(2, -1).double().sum(1)) / np.log(2), rtol=2e-4, atol=1e-2)
+
+
+def test_conv_variants_bit_identical(dev, monkeypatch):
+    """The LDS-DMA 3x3 kernel, the generic kernel and every tile variant picked for different batch sizes give
+    bit-identical outputs (one reduction order per layer) -- the batch an image travels in never changes it."""
+    import subprocess, sys, os
+    from dc_vic_amd import ops
+    x = rnd(12, 256, 64, 64, seed=50).to(dev)
+    w = rnd(256, 256, 3, 3, seed=51, scale=0.02).to(dev)
+    b = rnd(256, seed=52, scale=0.1).to(dev)
+    plan = ops.ConvPlan(w, b, "conv", pad=(1, 1))
+    full = plan(x)                                   # N=12 @64x64 -> enough workgroups for the DMA kernel
+    one = plan(x[5:6].contiguous())                  # N=1 -> a small-tile generic variant
+    assert torch.equal(one[0], full[5])
+    two = plan(x[4:6].contiguous())
+    assert torch.equal(two[1], full[5])
+    # forced generic kernel in a child process (the switch is read once per process)
+    code = ("import torch,sys;sys.path.insert(0,%r);from dc_vic_amd import ops;"
+            "g=torch.Generator().manual_seed(50);x=torch.randn(12,256,64,64,generator=g).cuda();"
+            "g=torch.Generator().manual_seed(51);w=(torch.randn(256,256,3,3,generator=g)*0.02).cuda();"
+            "g=torch.Generator().manual_seed(52);b=(torch.randn(256,generator=g)*0.1).cuda();"
+            "o=ops.ConvPlan(w,b,'conv',pad=(1,1))(x);torch.save(o.cpu(),sys.argv[1])") % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    import tempfile
+    with tempfile.TemporaryDirectory() as td:
+        p = os.path.join(td, "o.pt")
+        env = dict(os.environ, DCVIC_CONV_DMA="0")
+        subprocess.check_call([sys.executable, "-c", code, p], env=env)
+        gen = torch.load(p)
+    assert torch.equal(gen, full.cpu())

@@ -1,0 +1,58 @@
+// Diagnostic: what fp32-MFMA rate does this MI355X sustain (a) from registers, (b) with the conv kernel's
+// LDS read pattern beside it?  Also reports the in-kernel clock (s_memtime / s_memrealtime).
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+template <int MODE>
+__global__ __launch_bounds__(512, 2) void k(float* out, int iters, unsigned long long* clk) {
+    __shared__ float lds[12288];
+    for (int i = threadIdx.x; i < 12288; i += blockDim.x) lds[i] = (float)((i * 2654435761u) >> 8) * 1e-9f;
+    __syncthreads();
+    f32x16 acc[4];
+    for (int j = 0; j < 4; ++j) for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+    float a0 = threadIdx.x * 1e-3f, a1 = a0 + 1.f, b0 = a0 * 0.5f, b1 = b0 + 2.f;
+    const float* p = lds + (threadIdx.x & 63);
+    unsigned long long t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int s = 0; s < 36; ++s) {
+            if (MODE == 1) { a0 = p[s * 128]; a1 = p[s * 128 + 64]; b0 = p[4608 + s * 68]; b1 = p[4608 + s * 68 + 34]; }
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[1], 0, 0, 0);
+            acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[2], 0, 0, 0);
+            acc[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[3], 0, 0, 0);
+        }
+    }
+    unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+    float s = 0;
+    for (int j = 0; j < 4; ++j) for (int r = 0; r < 16; ++r) s += acc[j][r];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+    if (threadIdx.x == 0 && blockIdx.x == 0) { clk[0] = t1 - t0; clk[1] = r1 - r0; }
+}
+
+template <int MODE>
+void run(const char* name, int blocks) {
+    float* out; unsigned long long* clk;
+    hipMalloc(&out, sizeof(float) * blocks * 512); hipMalloc(&clk, 16);
+    int iters = 400;
+    k<MODE><<<blocks, 512>>>(out, 10, clk);
+    hipDeviceSynchronize();
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    for (int rep = 0; rep < 3; ++rep) {
+        hipEventRecord(e0);
+        k<MODE><<<blocks, 512>>>(out, iters, clk);
+        hipEventRecord(e1); hipEventSynchronize(e1);
+        float ms; hipEventElapsedTime(&ms, e0, e1);
+        unsigned long long h[2]; hipMemcpy(h, clk, 16, hipMemcpyDeviceToHost);
+        double flops = (double)blocks * 8 /*waves*/ * iters * 36 * 4 * 4096.0;
+        printf("%s blocks=%d: %.3f ms  %.1f TFLOP/s  in-kernel clock %.3f GHz\n", name, blocks, ms, flops / ms * 1e-9,
+               (double)h[0] / (double)h[1] * 0.1);
+    }
+}
+int main() {
+    run<0>("mfma-only (registers)", 512);
+    run<1>("mfma + conv-like ds_read", 512);
+    run<0>("mfma-only 1 WG/CU", 256);
+    return 0;
+}
