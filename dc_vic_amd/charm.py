@@ -39,6 +39,31 @@ class SliceTransform(nn.Module):
         x = self.model[2](x, act=ops.ACT_RELU)
         return self.model[4](x, out=out, act=act)
 
+    def _rest_plan(self, n_lead: int):
+        """First conv restricted to input channels [n_lead:] (the leading hyperprior channels are handled by a
+        stacked launch, see Minnen20CharmContextModel._hyper_partials); None when nothing is left."""
+        c0 = self.model[0]
+        key = (c0.weight.data_ptr(), c0.weight._version, n_lead)
+        if getattr(self, "_rest_key", None) != key:
+            w = c0.weight.detach()
+            self._rest = ops.ConvPlan(w[:, n_lead:].contiguous(), c0.bias, "conv", pad=(2, 2)) if w.shape[1] > n_lead else None
+            self._zero = torch.zeros((1, w.shape[0]), dtype=torch.float32, device=w.device)
+            self._rest_key = key
+        return self._rest
+
+    def forward_from_partial(self, partial: Tensor, n_lead: int, rest_srcs, out: Optional[Tensor] = None, act: int = ops.ACT_NONE) -> Tensor:
+        """Same result, bit for bit, as forward(cat[lead, rest]): `partial` holds the first conv's accumulators after
+        the `n_lead` leading input channels (no bias); the remaining channels continue the same fma chain."""
+        plan = self._rest_plan(n_lead)
+        if plan is not None:
+            x = plan(rest_srcs, act=ops.ACT_RELU, init=partial)
+        else:
+            c0 = self.model[0]
+            x = ops.chan_affine(partial, self._zero, c0.bias.detach().view(1, -1).contiguous())
+            x = ops.activation(x, ops.ACT_RELU, out=x)
+        x = self.model[2](x, act=ops.ACT_RELU)
+        return self.model[4](x, out=out, act=act)
+
 
 @CONTEXTMODEL_REGISTRY.register()
 class Minnen20CharmContextModel(nn.Module):
@@ -62,6 +87,23 @@ class Minnen20CharmContextModel(nn.Module):
 
     def _n_support(self, i: int) -> int:
         return i if self.max_support_slices < 0 else min(i, self.max_support_slices)
+
+    def _hyper_partials(self, hyper_mean: Tensor, hyper_scale: Tensor):
+        """The hyperprior channels lead the input of every transform's first conv and do not depend on decoded
+        slices, so their contribution is computed for all 3 x num_slices transforms by two large stacked launches
+        instead of 18 small ones inside the sequential slice loop.  The accumulators are handed to the per-slice
+        convs through `init`, which continue the reduction over the support channels in the same order: results
+        are bit-identical to the unsplit convolution."""
+        ms, ss, ls = self.mean_slice_transforms, self.scale_slice_transforms, self.lrp_slice_transforms
+        key = tuple((t.model[0].weight.data_ptr(), t.model[0].weight._version) for t in list(ms) + list(ss) + list(ls))
+        hm = self.hyper_half
+        if getattr(self, "_hp_key", None) != key:
+            wm = torch.cat([t.model[0].weight.detach()[:, :hm] for t in list(ms) + list(ls)], 0).contiguous()
+            ws = torch.cat([t.model[0].weight.detach()[:, :hm] for t in ss], 0).contiguous()
+            self._hp_mean = ops.ConvPlan(wm, None, "conv", pad=(2, 2))
+            self._hp_scale = ops.ConvPlan(ws, None, "conv", pad=(2, 2))
+            self._hp_key = key
+        return self._hp_mean(hyper_mean), self._hp_scale(hyper_scale)
 
     def run(self, y: Optional[Tensor], hyper_out: Tensor, entropy_model_y: GaussianMeanScaleConditional,
             symbols_in: Optional[Callable[[int, Tensor], Tensor]] = None, want_likelihood: bool = True,
@@ -90,6 +132,10 @@ class Minnen20CharmContextModel(nn.Module):
             if getattr(self, "_side_stream", None) is None or self._side_stream.device != dev:
                 self._side_stream = torch.cuda.Stream(device=dev)
             side = self._side_stream
+        split = os.environ.get("DCVIC_CHARM_SPLIT", "1") != "0"
+        if split:
+            Pm, Ps = self._hyper_partials(hyper_mean, hyper_scale)
+            c1 = self.mean_slice_transforms[0].model[0].out_channels      # 224
         for i in range(ns):
             sl = slice(i * sc, (i + 1) * sc)
             k = self._n_support(i)
@@ -102,10 +148,19 @@ class Minnen20CharmContextModel(nn.Module):
                 ev_fork = torch.cuda.Event(); ev_fork.record(main)
                 side.wait_event(ev_fork)
                 with torch.cuda.stream(side):
-                    self.scale_slice_transforms[i]([hyper_scale] + support, out=sigma)
+                    if split:
+                        self.scale_slice_transforms[i].forward_from_partial(Ps[:, i * c1:(i + 1) * c1], hm, support, out=sigma)
+                    else:
+                        self.scale_slice_transforms[i]([hyper_scale] + support, out=sigma)
                     ev_join = torch.cuda.Event(); ev_join.record(side)
-                self.mean_slice_transforms[i]([hyper_mean] + support, out=mu)
+                if split:
+                    self.mean_slice_transforms[i].forward_from_partial(Pm[:, i * c1:(i + 1) * c1], hm, support, out=mu)
+                else:
+                    self.mean_slice_transforms[i]([hyper_mean] + support, out=mu)
                 main.wait_event(ev_join)
+            elif split:
+                self.mean_slice_transforms[i].forward_from_partial(Pm[:, i * c1:(i + 1) * c1], hm, support, out=mu)
+                self.scale_slice_transforms[i].forward_from_partial(Ps[:, i * c1:(i + 1) * c1], hm, support, out=sigma)
             else:
                 self.mean_slice_transforms[i]([hyper_mean] + support, out=mu)
                 self.scale_slice_transforms[i]([hyper_scale] + support, out=sigma)
@@ -120,7 +175,11 @@ class Minnen20CharmContextModel(nn.Module):
                 sym[:, sl] = s_i
                 ops.gaussian_rate(None, sym[:, sl], mu, sigma, table, yq, None, None, None, None)
             # latent residual predictor: y_hat_i = yq + 0.5 tanh(lrp(cat[mean_support, yq]))
-            lrp = self.lrp_slice_transforms[i]([hyper_mean] + support + [yq], act=ops.ACT_HALF_TANH)
+            if split:
+                lrp = self.lrp_slice_transforms[i].forward_from_partial(Pm[:, (ns + i) * c1:(ns + i + 1) * c1], hm, support + [yq],
+                                                                        act=ops.ACT_HALF_TANH)
+            else:
+                lrp = self.lrp_slice_transforms[i]([hyper_mean] + support + [yq], act=ops.ACT_HALF_TANH)
             ops.add(yq, lrp, out=y_hat[:, sl])
         return dict(y_hat=y_hat, y_likelihood=lik, symbols=sym, indexes=idx, mu=ms[:, :Cy], sigma=ms[:, Cy:])
 

@@ -75,6 +75,25 @@ __global__ __launch_bounds__(NTHREADS, (MT * NT >= 8) ? 2 : ((MT * NT >= 4) ? 3 
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
 
+    if (K.init) {
+        // continue a reduction started by another launch (CHARM: the hyperprior part of a transform's first conv is
+        // computed for all slices up front); the fma chain then runs on exactly as in a single launch
+        const long long HWi = (long long)K.Hfull * K.Wfull;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const int oy = oy0 + pty[nt], ox = ox0 + ptx[nt];
+            if (oy >= K.Hout || ox >= K.Wout) continue;
+            const long long pix = (long long)(oy * K.osy + K.ooy) * K.Wfull + (ox * K.osx + K.oox);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int co = cotile * TC + (wm * MT + mt) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lane_k;
+                    if (co < K.Cout) acc[mt][nt][r] = K.init[(long long)n * K.init_bs + (long long)co * HWi + pix];
+                }
+        }
+    }
+
     const long long HW = (long long)K.H * K.W;
     const float* wbase = K.wp + (long long)cotile * K.n_chunks * K.T * (KC * TC);
 
@@ -408,6 +427,7 @@ extern "C" int dcvic_conv2d_f32(const dcvic_conv_desc* d, const float* packed, c
     DCVIC_CHECK_ARG((long long)io->H * io->W < (1ll << 30) && (long long)io->Hfull * io->Wfull < (1ll << 30), "conv2d: plane too large");
     DCVIC_CHECK_ARG(!io->res || io->res_batch_stride >= (long long)d->Cout * io->Hfull * io->Wfull, "conv2d: res batch stride too small");
     DCVIC_CHECK_ARG((io->aff_scale == nullptr) == (io->aff_shift == nullptr), "conv2d: affine needs both scale and shift");
+    DCVIC_CHECK_ARG(!io->init || io->init_batch_stride >= (long long)d->Cout * io->Hfull * io->Wfull, "conv2d: init batch stride too small");
     const int cls = d->cfg;
     DCVIC_CHECK_ARG(cls >= 0 && cls <= 3, "conv2d: bad cfg %d", cls);
     init_num_cu();
@@ -424,6 +444,7 @@ extern "C" int dcvic_conv2d_f32(const dcvic_conv_desc* d, const float* packed, c
     K.out = io->out; K.out_bs = io->out_batch_stride; K.bias = io->bias; K.act = io->act;
     K.res = io->res; K.res_bs = io->res_batch_stride; K.affs = io->aff_scale; K.afft = io->aff_shift; K.aff_bs = io->aff_batch_stride;
     K.wp = packed;
+    K.init = io->init; K.init_bs = io->init_batch_stride;
     int dy_min = 127, dy_max = -128, dx_min = 127, dx_max = -128;
     // taps must form a regular grid (true for every conv / transposed-conv phase the desc builders emit)
     {

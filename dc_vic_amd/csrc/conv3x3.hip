@@ -174,7 +174,7 @@ __global__ __launch_bounds__(D_THREADS, 2) void conv3x3_dma_kernel(const ConvKAr
 
 int dcvic_try_conv3x3_dma(const ConvKArgs& Kin, int n_src, bool upsample, int cls, hipStream_t st) {
     const ConvKArgs& K = Kin;
-    if (K.halves != 2 || upsample || cls != 0 || K.TWlog != 5) return 1;   // halves == 2 <=> 3x3/s1/p1 family, channels % 8 == 0
+    if (K.halves != 2 || upsample || cls != 0 || K.TWlog != 5 || K.init) return 1;   // halves == 2 <=> 3x3/s1/p1 family, channels % 8 == 0
     if ((long long)K.H * K.W * KC >= (1ll << 31)) return 1;
     ConvKArgs A = K;
     A.tiles_y = (K.Hout + D_TH - 1) / D_TH;

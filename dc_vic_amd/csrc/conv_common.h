@@ -25,6 +25,8 @@ struct ConvKArgs {
     const float* afft;
     long long aff_bs;
     const float* wp;
+    const float* init;        // accumulators start from init[n][co][pix] (same geometry as out) instead of 0
+    long long init_bs;
     int TX, dy0, dx0, dstep;  // taps form a grid: t = iy*TX + ix, dy = dy0 + iy*dstep, dx = dx0 + ix*dstep
     int nslots;               // ceil(plane / NTHREADS)
     int TWlog, tiles_x, tiles_y;

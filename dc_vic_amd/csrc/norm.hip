@@ -20,39 +20,47 @@ __device__ __forceinline__ float block_sum(float v, float* red) {
     return t;
 }
 
-// One workgroup per (n, group).  The group's cg*HW floats are contiguous in NCHW.
-// Two-pass statistics (mean, then centred variance) like torch's CPU kernel -- no E[x^2]-m^2.
+__device__ __forceinline__ double block_sum_d(double v, double* red) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    __syncthreads();
+    if (lane == 0) red[w] = v;
+    __syncthreads();
+    double t = 0.0;
+    for (int i = 0; i < nw; ++i) t += red[i];
+    return t;
+}
+
+// One workgroup per (n, group).  The group's cg*HW floats are contiguous in NCHW: 2 reads + 1 write of the group.
 __global__ __launch_bounds__(512) void groupnorm_kernel(const float* __restrict__ x, long long x_bs, float* __restrict__ y,
                                                         long long y_bs, const float* __restrict__ gamma,
                                                         const float* __restrict__ beta, int C, int HW, int groups, float eps,
                                                         int act) {
-    __shared__ float red[16];
+    __shared__ double redd[16];
     const int n = blockIdx.x / groups, g = blockIdx.x % groups;
     const int cg = C / groups;
     const long long len = (long long)cg * HW;
     const float* xp = x + (long long)n * x_bs + (long long)g * cg * HW;
     float* yp = y + (long long)n * y_bs + (long long)g * cg * HW;
     const bool vec = ((len & 3) == 0) && ((reinterpret_cast<uintptr_t>(xp) & 15) == 0) && ((reinterpret_cast<uintptr_t>(yp) & 15) == 0) && ((HW & 3) == 0);
-    float s = 0.f;
-    if (vec) {
-        const float4* x4 = reinterpret_cast<const float4*>(xp);
-        for (long long i = threadIdx.x; i < len / 4; i += blockDim.x) { float4 v = x4[i]; s += (v.x + v.y) + (v.z + v.w); }
-    } else {
-        for (long long i = threadIdx.x; i < len; i += blockDim.x) s += xp[i];
-    }
-    const float mean = block_sum(s, red) / (float)len;
-    float q = 0.f;
+    // one statistics pass: sum and sum of squares accumulated in fp64 (E[x^2] - mean^2 is then exact to fp32
+    // accuracy, no second read of the group), reduced in a fixed order
+    double s = 0.0, q = 0.0;
     if (vec) {
         const float4* x4 = reinterpret_cast<const float4*>(xp);
         for (long long i = threadIdx.x; i < len / 4; i += blockDim.x) {
-            float4 v = x4[i];
-            const float a = v.x - mean, b = v.y - mean, c = v.z - mean, d = v.w - mean;
-            q += (a * a + b * b) + (c * c + d * d);
+            const float4 v = x4[i];
+            s += ((double)v.x + (double)v.y) + ((double)v.z + (double)v.w);
+            q += ((double)v.x * v.x + (double)v.y * v.y) + ((double)v.z * v.z + (double)v.w * v.w);
         }
     } else {
-        for (long long i = threadIdx.x; i < len; i += blockDim.x) { const float a = xp[i] - mean; q += a * a; }
+        for (long long i = threadIdx.x; i < len; i += blockDim.x) { const double v = xp[i]; s += v; q += v * v; }
     }
-    const float var = block_sum(q, red) / (float)len;
+    const double S = block_sum_d(s, redd), Q = block_sum_d(q, redd);
+    const double mean_d = S / (double)len;
+    const float mean = (float)mean_d;
+    const float var = (float)fmax(Q / (double)len - mean_d * mean_d, 0.0);
     const float rstd = 1.0f / sqrtf(var + eps);
     if (vec) {
         const float4* x4 = reinterpret_cast<const float4*>(xp);
@@ -113,22 +121,40 @@ extern "C" int dcvic_layernorm_c_f32(const float* x, float* y, const float* gamm
     return DCVIC_OK;
 }
 
-// softmax over C of [N][C][P], in place; thread per column p.
+// softmax over C of [N][C][P], in place.  A workgroup owns 64 columns; its 4 waves split the rows (c = wave mod 4),
+// keep an online (max, sum) pair per lane, merge the four pairs through LDS, then write exp(x - M) / S:
+// 2 reads + 1 write of the map (coalesced 256-B rows) and N * P/64 workgroups.
 __global__ __launch_bounds__(256) void softmax_c_kernel(float* __restrict__ x, int C, int P) {
-    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    __shared__ float sm[4][64], ss[4][64];
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int p = blockIdx.x * 64 + tx;
     const int n = blockIdx.y;
-    if (p >= P) return;
-    float* xp = x + (long long)n * C * P + p;
-    float m = -INFINITY;
-    for (int c = 0; c < C; ++c) m = fmaxf(m, xp[(long long)c * P]);
-    float s = 0.f;
-    for (int c = 0; c < C; ++c) { const float e = expf(xp[(long long)c * P] - m); xp[(long long)c * P] = e; s += e; }
-    for (int c = 0; c < C; ++c) xp[(long long)c * P] = xp[(long long)c * P] / s;
+    const bool live = p < P;
+    float* xp = x + (long long)n * C * P + (live ? p : 0);
+    float m = -INFINITY, sum = 0.f;
+    if (live) {
+        for (int c = ty; c < C; c += 4) {
+            const float v = xp[(long long)c * P];
+            if (v > m) { sum = sum * expf(m - v) + 1.f; m = v; }
+            else sum += expf(v - m);
+        }
+    }
+    sm[ty][tx] = m; ss[ty][tx] = sum;
+    __syncthreads();
+    float M = fmaxf(fmaxf(sm[0][tx], sm[1][tx]), fmaxf(sm[2][tx], sm[3][tx]));
+    float S = 0.f;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) S += (sm[g][tx] == -INFINITY) ? 0.f : ss[g][tx] * expf(sm[g][tx] - M);
+    if (live) {
+        const float inv = 1.0f / S;
+        for (int c = ty; c < C; c += 4) xp[(long long)c * P] = expf(xp[(long long)c * P] - M) * inv;
+    }
 }
 
 extern "C" int dcvic_softmax_c_f32(float* x, int N, int C, int P, void* stream) {
     DCVIC_CHECK_ARG(x && N > 0 && C > 0 && P > 0, "softmax_c: bad argument");
-    dim3 grid(dcvic_cdiv(P, 256), N);
+    DCVIC_CHECK_ARG(N <= 65535, "softmax_c: batch too large");
+    dim3 grid(dcvic_cdiv(P, 64), N);
     softmax_c_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(x, C, P);
     DCVIC_CHECK_LAUNCH("softmax_c");
     return DCVIC_OK;

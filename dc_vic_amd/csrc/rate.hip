@@ -33,14 +33,18 @@ __global__ __launch_bounds__(256) void gaussian_rate_kernel(const float* __restr
                                                             float* __restrict__ y_hat, long long yh_bs,
                                                             int32_t* __restrict__ sym_out, int32_t* __restrict__ index_out,
                                                             long long si_bs, float* __restrict__ lik_out,
-                                                            float* __restrict__ bits_out, long long CHW) {
+                                                            double* __restrict__ partial, long long CHW) {
     __shared__ double red[4];
     __shared__ float tab[64];
-    const int n = blockIdx.x;
+    const int n = blockIdx.y;
     for (int i = threadIdx.x; i < n_scales && i < 64; i += blockDim.x) tab[i] = table[i];
     __syncthreads();
     double acc = 0.0;
-    for (long long i = threadIdx.x; i < CHW; i += blockDim.x) {
+    // block b of image n owns the contiguous span [b*span, (b+1)*span): the decomposition depends on CHW only,
+    // so the per-image sum has one fixed order whatever the batch size
+    const long long span = (CHW + gridDim.x - 1) / gridDim.x;
+    const long long i_end = min(CHW, (long long)(blockIdx.x + 1) * span);
+    for (long long i = (long long)blockIdx.x * span + threadIdx.x; i < i_end; i += blockDim.x) {
         const float m = mu[n * ms_bs + i];
         const float s = fmaxf(sigma[n * ms_bs + i], 0.11f);
         float sym;
@@ -54,7 +58,7 @@ __global__ __launch_bounds__(256) void gaussian_rate_kernel(const float* __restr
             for (int t = 0; t < n_scales - 1; ++t) ix -= (s <= tab[t]) ? 1 : 0;
             index_out[n * si_bs + i] = ix;
         }
-        if (lik_out || bits_out) {
+        if (lik_out || partial) {
             const float v = fabsf(__fsub_rn(yh, m));
             const float up = std_cumulative((0.5f - v) / s);
             const float lo = std_cumulative((-0.5f - v) / s);
@@ -63,24 +67,45 @@ __global__ __launch_bounds__(256) void gaussian_rate_kernel(const float* __restr
             acc += (double)logf(p);
         }
     }
-    if (bits_out) {
+    if (partial) {
         const double t = block_sum_d(acc, red);
-        if (threadIdx.x == 0) bits_out[n] += (float)(-t / 0.693147180559945309417);
+        if (threadIdx.x == 0) partial[(long long)n * gridDim.x + blockIdx.x] = t;
     }
+}
+
+// bits[n] += -(sum of the image's block partials, ascending) / ln 2
+__global__ void rate_finish_kernel(const double* __restrict__ partial, int nb, float* __restrict__ bits_out) {
+    const int n = threadIdx.x;          // one thread per image (N <= 1024, checked by the caller)
+    double t = 0.0;
+    for (int b = 0; b < nb; ++b) t += partial[(long long)n * nb + b];
+    bits_out[n] += (float)(-t / 0.693147180559945309417);
+}
+
+extern "C" int dcvic_rate_blocks(long long CHW) {
+    long long b = (CHW + 2047) / 2048;
+    return (int)(b < 1 ? 1 : (b > 64 ? 64 : b));
 }
 
 extern "C" int dcvic_gaussian_rate_f32(const float* y, long long y_bs, const int32_t* sym_in, const float* mu,
                                        const float* sigma, long long ms_bs, const float* scale_table, int n_scales,
                                        float* y_hat, long long yh_bs, int32_t* sym_out, int32_t* index_out, long long si_bs,
-                                       float* lik_out, float* bits_out, int N, int C, int HW, void* stream) {
+                                       float* lik_out, float* bits_out, double* partial_ws, int N, int C, int HW, void* stream) {
     DCVIC_CHECK_ARG(mu && sigma && scale_table && N > 0 && C > 0 && HW > 0, "gaussian_rate: bad argument");
     DCVIC_CHECK_ARG((y != nullptr) != (sym_in != nullptr), "gaussian_rate: exactly one of y / sym_in must be given");
     DCVIC_CHECK_ARG(n_scales >= 2 && n_scales <= 64, "gaussian_rate: n_scales %d", n_scales);
     const long long CHW = (long long)C * HW;
     DCVIC_CHECK_ARG(ms_bs >= CHW && si_bs >= CHW, "gaussian_rate: batch stride too small");
-    gaussian_rate_kernel<<<N, 256, 0, (hipStream_t)stream>>>(y, y_bs, sym_in, mu, sigma, ms_bs, scale_table, n_scales, y_hat,
-                                                           yh_bs, sym_out, index_out, si_bs, lik_out, bits_out, CHW);
+    DCVIC_CHECK_ARG(!bits_out || partial_ws, "gaussian_rate: bits_out needs a partial-sum workspace of N * dcvic_rate_blocks(C*HW) doubles");
+    DCVIC_CHECK_ARG(N <= 65535 && (!bits_out || N <= 1024), "gaussian_rate: batch too large (bits_out: <= 1024 images per call)");
+    const int nb = dcvic_rate_blocks(CHW);
+    dim3 grid(nb, N);
+    gaussian_rate_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(y, y_bs, sym_in, mu, sigma, ms_bs, scale_table, n_scales, y_hat,
+                                                              yh_bs, sym_out, index_out, si_bs, lik_out, bits_out ? partial_ws : nullptr, CHW);
     DCVIC_CHECK_LAUNCH("gaussian_rate");
+    if (bits_out) {
+        rate_finish_kernel<<<1, N, 0, (hipStream_t)stream>>>(partial_ws, nb, bits_out);
+        DCVIC_CHECK_LAUNCH("rate_finish");
+    }
     return DCVIC_OK;
 }
 

@@ -4,6 +4,7 @@ entropy coder).  Nothing here falls back to torch ops."""
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import List, Optional, Sequence, Tuple
 
 import numpy as np
@@ -116,7 +117,27 @@ class ConvPlan:
             w = w.view(w.shape[0], w.shape[1], 1, 1)
         self._w = w
         self.phases: List[list] = []      # [desc, {tile class: packed weights}, py, px]
-        if kind == "conv":
+        self.ups_phases = False
+        if kind == "conv" and upsample and tuple(w.shape[2:]) == (3, 3) and pad == (1, 1) and stride == 1 \
+                and os.environ.get("DCVIC_UPS_PHASES", "1") != "0":
+            # nearest-x2 + conv3x3 == four 2x2 sub-pixel convolutions on the low-res input (4/9 of the flops):
+            # output row 2m+py reads low-res rows {m-1, m} (py=0) or {m, m+1} (py=1) with the taps that land on
+            # the same low-res row pre-added.  Zero padding is preserved (row -1 / row H are out of the image).
+            self.Cout, self.Cin, self.KH, self.KW = w.shape
+            self.ups_phases = True
+            self._wphase = []
+            for py in (0, 1):
+                rows = [w[:, :, 0], w[:, :, 1] + w[:, :, 2]] if py == 0 else [w[:, :, 0] + w[:, :, 1], w[:, :, 2]]
+                for px in (0, 1):
+                    cols = []
+                    for r in rows:       # r: [Cout, Cin, 3]
+                        cols.append(torch.stack([r[:, :, 0], r[:, :, 1] + r[:, :, 2]] if px == 0 else [r[:, :, 0] + r[:, :, 1], r[:, :, 2]], dim=-1))
+                    weff = torch.stack(cols, dim=2).contiguous()    # [Cout, Cin, 2, 2]
+                    d = ConvDesc()
+                    check(lib().dcvic_conv_desc_init(C.byref(d), self.Cin, self.Cout, 2, 2, 1, 1 - py, 1 - px, 0), "conv_desc_init")
+                    self.phases.append([d, {}, py, px])
+                    self._wphase.append(weff)
+        elif kind == "conv":
             self.Cout, self.Cin, self.KH, self.KW = w.shape
             d = ConvDesc()
             check(lib().dcvic_conv_desc_init(C.byref(d), self.Cin, self.Cout, self.KH, self.KW, stride, pad[0], pad[1],
@@ -153,7 +174,8 @@ class ConvPlan:
         return H, W  # overridden by the caller for strided / valid convs
 
     def __call__(self, srcs, out: Optional[Tensor] = None, act: int = ACT_NONE, res: Optional[Tensor] = None,
-                 affine: Optional[Tuple[Tensor, Tensor]] = None, out_hw: Optional[Tuple[int, int]] = None) -> Tensor:
+                 affine: Optional[Tuple[Tensor, Tensor]] = None, out_hw: Optional[Tuple[int, int]] = None,
+                 init: Optional[Tensor] = None, use_bias: bool = True) -> Tensor:
         if isinstance(srcs, Tensor):
             srcs = [srcs]
         N, _, H, W = _chk4(srcs[0], "conv src0")
@@ -183,8 +205,13 @@ class ConvPlan:
                 raise ValueError("conv sources disagree in shape")
             io.src[i].ptr = s.data_ptr(); io.src[i].C = c_; io.src[i].batch_stride = _bs(s)
         io.out = out.data_ptr(); io.out_batch_stride = _bs(out)
-        io.bias = self.bias.data_ptr() if self.bias is not None else None
+        io.bias = self.bias.data_ptr() if (self.bias is not None and use_bias) else None
         io.act = act
+        if init is not None:
+            if tuple(init.shape) != tuple(out.shape):
+                raise ValueError("conv init shape mismatch")
+            _chk4(init, "conv init")
+            io.init = init.data_ptr(); io.init_batch_stride = _bs(init)
         if res is not None:
             if tuple(res.shape) != tuple(out.shape):
                 raise ValueError("conv residual shape mismatch")
@@ -199,9 +226,9 @@ class ConvPlan:
             if sc.shape[0] not in (1, N):
                 raise ValueError("conv affine batch must be 1 or N")
         st = _stream()
-        for ph in self.phases:
+        for phi, ph in enumerate(self.phases):
             d, packs, py, px = ph
-            if self.kind == "convT" and self.KH == 5:
+            if self.ups_phases or (self.kind == "convT" and self.KH == 5):
                 io.Hout, io.Wout = H, W
                 io.osy = io.osx = 2
                 io.ooy, io.oox = py, px
@@ -215,7 +242,7 @@ class ConvPlan:
             d.cfg = cls
             packed = packs.get(cls)
             if packed is None:
-                packed = packs[cls] = self._pack(d, self._w)
+                packed = packs[cls] = self._pack(d, self._wphase[phi] if self.ups_phases else self._w)
             if _EVENTS is not None:
                 e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
                 e0.record()
@@ -418,10 +445,13 @@ def gaussian_rate(y: Optional[Tensor], sym_in: Optional[Tensor], mu: Tensor, sig
                 raise ValueError("symbol/index/likelihood buffers must share a batch stride")
     if si_bs is None:
         si_bs = Cc * H * W
+    ws = None
+    if bits_out is not None:
+        ws = torch.empty(N * lib().dcvic_rate_blocks(C.c_longlong(Cc * H * W)), dtype=torch.float64, device=mu.device)
     check(lib().dcvic_gaussian_rate_f32(_p(y), C.c_longlong(_bs(y) if y is not None else 0), _p(sym_in), _p(mu), _p(sigma),
                                         C.c_longlong(_bs(mu)), _p(scale_table), scale_table.numel(), _p(y_hat),
                                         C.c_longlong(_bs(y_hat) if y_hat is not None else 0), _p(sym_out), _p(index_out),
-                                        C.c_longlong(si_bs), _p(lik_out), _p(bits_out), N, Cc, H * W, _stream()), "gaussian_rate")
+                                        C.c_longlong(si_bs), _p(lik_out), _p(bits_out), _p(ws), N, Cc, H * W, _stream()), "gaussian_rate")
 
 
 def eb_rate(z: Optional[Tensor], packs, z_hat: Optional[Tensor], sym_out: Optional[Tensor], lik_out: Optional[Tensor],

@@ -109,6 +109,9 @@ typedef struct {
     const float* aff_scale;   /* v = v*(1+scale[n][co]) + shift[n][co] after res, or NULL */
     const float* aff_shift;
     long long aff_batch_stride; /* 0 = same vector for every image */
+    const float* init;        /* accumulators start from init[n][co][pix] (out geometry) instead of 0, or NULL:
+                                 lets a reduction over input channels be split across launches bit-exactly */
+    long long init_batch_stride;
 } dcvic_conv_io;
 
 /* Standard k x k convolution (pad_t/pad_l zeros; bottom/right padding is implied by Hout/Wout). */
@@ -205,12 +208,15 @@ int dcvic_argmax_lut_f32(const float* logits, int64_t* idx, float* latent, const
  * minnen20_charm_context_model.py:96,148,164,199:
  *   sym = rint(y - mu); y_hat = sym + mu; p = max(Phi((.5-|sym|)/s) - Phi((-.5-|sym|)/s), 1e-9), s = max(sigma, .11)
  *   index = 63 - #{table[:-1] >= s}.  decode mode (y == NULL): y_hat = sym_in + mu.
- * bits[n] += -log2(p) summed per image in a fixed order (deterministic tree).
+ * bits[n] += -log2(p) summed per image in a fixed order (per-block fp64 partials, then ascending).
  */
 int dcvic_gaussian_rate_f32(const float* y, long long y_bs, const int32_t* sym_in, const float* mu, const float* sigma,
                             long long ms_bs, const float* scale_table, int n_scales, float* y_hat, long long yh_bs,
                             int32_t* sym_out, int32_t* index_out, long long si_bs, float* lik_out, float* bits_out,
+                            double* partial_ws /* N * dcvic_rate_blocks(C*HW) doubles, needed with bits_out */,
                             int N, int C, int HW, void* stream);
+/* Workgroups per image of the rate kernels (a function of C*HW only, so sums are batch-invariant). */
+int dcvic_rate_blocks(long long CHW);
 /* EntropyBottleneck eval forward (entropy_bottleneck.py:19-28 -> CompressAI, App-B):
  * z_hat = rint(z - med) + med; p = max(|sig(s*up) - sig(s*lo)|, 1e-9); symbols = rint(z - med).
  * decode mode (z == NULL): z_hat = float(sym_in) + med (EntropyBottleneck.decompress dequantisation). */

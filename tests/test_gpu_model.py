@@ -201,3 +201,16 @@ def test_ragged_and_kodak_shape(model):
         from dc_vic_amd.codec_utils import HeaderHandler
         hd = HeaderHandler().decode(r["string_list"][0])
         assert hd["img_size"] == shape[2:] and hd["quality_ind"] == q
+
+
+def test_charm_split_and_streams_bit_identical(model, monkeypatch):
+    """The stacked hyperprior partial convs (accumulator hand-over through `init`) and the two-stream schedule are
+    pure re-schedulings: symbols, cdf indexes and y_hat are bit-identical to the plain sequential CHARM."""
+    x = img((3, 3, 128, 192), 106)
+    monkeypatch.setenv("DCVIC_CHARM_SPLIT", "0"); monkeypatch.setenv("DCVIC_CHARM_STREAMS", "0")
+    a = model.compress_batch(x, 1)
+    monkeypatch.setenv("DCVIC_CHARM_SPLIT", "1"); monkeypatch.setenv("DCVIC_CHARM_STREAMS", "1")
+    b = model.compress_batch(x, 1)
+    assert torch.equal(a["y_symbols"], b["y_symbols"]) and torch.equal(a["y_indexes"], b["y_indexes"])
+    assert torch.equal(a["y_hat"], b["y_hat"])
+    assert a["string_lists"] == b["string_lists"]
