@@ -84,7 +84,8 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
-    if world > 1:
+    if world > 1 or "TORCHELASTIC_RUN_ID" in os.environ or os.environ.get("DCVIC_FORCE_DIST") == "1":
+        # launched by torch.distributed.run: take the collective path even at world size 1 (same code as N > 1)
         import torch.distributed as dist_
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist_.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)

@@ -215,7 +215,22 @@ class HyperpriorVicModel(BaseModel):
 
     # hyperprior_vic_model.py:80-82
     def likelihood_to_bit(self, likelihood: Tensor, num_pixel: int):
-        raise NotImplementedError("bits are reduced inside the rate kernels; see run_model / compress")
+        """(bitcost, bitcost / num_pixel) over the whole tensor, as 0-dim tensors like the reference."""
+        bits = ops.neglog2_sum(likelihood).double().sum()
+        return bits, bits / num_pixel
+
+    # hyperprior_vic_model.py:66-78
+    def get_rate_summary_dict(self, out_dict: Dict, num_pixel: int) -> Dict[str, Tensor]:
+        lk, qlk = out_dict["likelihoods"], out_dict["q_likelihoods"]
+        _, y_bpp = self.likelihood_to_bit(lk["y"], num_pixel)
+        _, z_bpp = self.likelihood_to_bit(lk["z"], num_pixel)
+        if qlk["y"] is lk["y"] and qlk["z"] is lk["z"]:
+            yq_bpp, zq_bpp = y_bpp, z_bpp          # eval mode: both likelihoods are the quantised one
+        else:
+            _, yq_bpp = self.likelihood_to_bit(qlk["y"], num_pixel)
+            _, zq_bpp = self.likelihood_to_bit(qlk["z"], num_pixel)
+        return dict(y_likelihood=lk["y"], z_likelihood=lk["z"], bpp=y_bpp + z_bpp, y_q_likelihood=qlk["y"],
+                    z_q_likelihood=qlk["z"], qbpp=yq_bpp + zq_bpp)
 
     # ------------------------------------------------------------------ VQ encode (137-246)
     def _vq_encode_split(self, real_images: Tensor) -> Tensor:
@@ -243,7 +258,13 @@ class HyperpriorVicModel(BaseModel):
     def vq_encode(self, real_images: Tensor, vq_indices: Optional[Tensor] = None, want_feat: bool = False):
         """Returns (gt_vq_latent, gt_vq_indices[, feat = cat[latent, onehot]])."""
         if vq_indices is not None:
-            raise NotImplementedError("pre-computed vq_indices are a training-dataset feature")
+            # pre-computed tokens (scripts/build_openimage_val_dataset.py -> binary_rate_search / beta_selection callers)
+            idx = vq_indices.to(real_images.device).long()
+            zq = self.vq_indices_to_latent(idx)
+            if want_feat:
+                _, _, feat = ops.vq_argmin(zq, self.vq_model.quantize.embedding.weight, want_zq=False, want_feat=True)
+                return zq, idx, feat
+            return zq, idx
         N, _, H, W = real_images.shape
         _z = self._vq_encode_split(real_images) if max(H, W) > SPLIT_DECODE_RESOLUTION else self.vq_model.encode(real_images)
         assert not (max(H, W) > 1024 and self.n_embed > 1024), "_vq_quantize_split is only needed for n_embed > 1024"
@@ -345,6 +366,20 @@ class HyperpriorDualCondVicModel(HyperpriorVicModel):
 
     def _run_context(self, y, hyper_out, want_symbols, bits_y):
         raise NotImplementedError("only the CHARM variant (HyperpriorCharmDualCondVicModel) is shipped")
+
+    # hyperprior_dc_vic_model.py:120-170 (inference branch: betas must be given)
+    def data_preprocess(self, real_images: Tensor, vq_indices: Optional[Tensor] = None, beta_rate=None, beta_vq=None,
+                        is_train: bool = True, fix_entropy_models: bool = False, fusion_w: Optional[float] = None,
+                        sample_batch_beta: bool = False) -> dict:
+        if is_train:
+            raise NotImplementedError("dc_vic_amd implements the inference path only")
+        if beta_rate is None or beta_vq is None:
+            raise ValueError('"beta_rate" and "beta_vq" must be specified if is_train=False')
+        real_images = self.img_preprocess(real_images, is_train=False)
+        if vq_indices is not None:
+            vq_indices = vq_indices.to(self.device)
+        return dict(real_images=real_images, beta_rate=beta_rate, beta_vq=beta_vq, vq_indices=vq_indices,
+                    fix_entropy_models=fix_entropy_models, fusion_w=fusion_w)
 
     # ------------------------------------------------------------------ run_model (112-118, 208-274)
     @torch.no_grad()

@@ -183,3 +183,35 @@ extern "C" int dcvic_eb_rate_f32(const float* z, const int32_t* sym_in, const fl
     DCVIC_CHECK_LAUNCH("eb_rate");
     return DCVIC_OK;
 }
+
+// bits[n] = -(sum over one image of ln x) / ln 2        (likelihood_to_bit, hyperprior_vic_model.py:80-82)
+__global__ __launch_bounds__(256) void neglog2_partial_kernel(const float* __restrict__ x, long long x_bs, double* __restrict__ partial,
+                                                              long long CHW) {
+    __shared__ double red[4];
+    const int n = blockIdx.y;
+    const long long span = (CHW + gridDim.x - 1) / gridDim.x;
+    const long long i_end = min(CHW, (long long)(blockIdx.x + 1) * span);
+    double acc = 0.0;
+    for (long long i = (long long)blockIdx.x * span + threadIdx.x; i < i_end; i += blockDim.x) acc += (double)logf(x[n * x_bs + i]);
+    const double t = block_sum_d(acc, red);
+    if (threadIdx.x == 0) partial[(long long)n * gridDim.x + blockIdx.x] = t;
+}
+
+__global__ void neglog2_finish_kernel(const double* __restrict__ partial, int nb, float* __restrict__ bits_out) {
+    const int n = threadIdx.x;
+    double t = 0.0;
+    for (int b = 0; b < nb; ++b) t += partial[(long long)n * nb + b];
+    bits_out[n] = (float)(-t / 0.693147180559945309417);
+}
+
+extern "C" int dcvic_neglog2_sum_f32(const float* x, long long x_bs, float* bits_out, double* partial_ws, int N, long long CHW,
+                                     void* stream) {
+    DCVIC_CHECK_ARG(x && bits_out && partial_ws && N > 0 && N <= 1024 && CHW > 0 && x_bs >= CHW, "neglog2_sum: bad argument");
+    const int nb = dcvic_rate_blocks(CHW);
+    dim3 grid(nb, N);
+    neglog2_partial_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(x, x_bs, partial_ws, CHW);
+    DCVIC_CHECK_LAUNCH("neglog2_partial");
+    neglog2_finish_kernel<<<1, N, 0, (hipStream_t)stream>>>(partial_ws, nb, bits_out);
+    DCVIC_CHECK_LAUNCH("neglog2_finish");
+    return DCVIC_OK;
+}

@@ -454,6 +454,15 @@ def gaussian_rate(y: Optional[Tensor], sym_in: Optional[Tensor], mu: Tensor, sig
                                         C.c_longlong(si_bs), _p(lik_out), _p(bits_out), _p(ws), N, Cc, H * W, _stream()), "gaussian_rate")
 
 
+def neglog2_sum(lik: Tensor) -> Tensor:
+    """Per-image bit cost -sum(log2 p) of a likelihood map [N, C, H, W] -> float32 [N]."""
+    N, Cc, H, W = _chk4(lik, "neglog2 lik")
+    out = torch.empty(N, dtype=torch.float32, device=lik.device)
+    ws = torch.empty(N * lib().dcvic_rate_blocks(C.c_longlong(Cc * H * W)), dtype=torch.float64, device=lik.device)
+    check(lib().dcvic_neglog2_sum_f32(_p(lik), C.c_longlong(_bs(lik)), _p(out), _p(ws), N, C.c_longlong(Cc * H * W), _stream()), "neglog2_sum")
+    return out
+
+
 def eb_rate(z: Optional[Tensor], packs, z_hat: Optional[Tensor], sym_out: Optional[Tensor], lik_out: Optional[Tensor],
             bits_out: Optional[Tensor], sym_in: Optional[Tensor] = None):
     ref = z if z is not None else sym_in

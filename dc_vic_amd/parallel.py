@@ -34,7 +34,7 @@ def gather_rate_table(table: np.ndarray, dist, device=None) -> np.ndarray:
     """all_gather of a per-image fp64 table [n_local, k] -> [sum n_local, k] in rank order.
     Ranks may hold different row counts (ragged shards): rows are padded to the maximum and trimmed."""
     table = np.ascontiguousarray(table, dtype=np.float64)
-    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+    if dist is None or not dist.is_initialized():
         return table
     world = dist.get_world_size()
     dev = device if device is not None else torch.device("cpu")

@@ -215,6 +215,9 @@ int dcvic_gaussian_rate_f32(const float* y, long long y_bs, const int32_t* sym_i
                             int32_t* sym_out, int32_t* index_out, long long si_bs, float* lik_out, float* bits_out,
                             double* partial_ws /* N * dcvic_rate_blocks(C*HW) doubles, needed with bits_out */,
                             int N, int C, int HW, void* stream);
+/* bits_out[n] = -sum(ln x[n][...]) / ln 2 over C*HW likelihoods (likelihood_to_bit, hyperprior_vic_model.py:80-82);
+ * partial_ws: N * dcvic_rate_blocks(CHW) doubles. */
+int dcvic_neglog2_sum_f32(const float* x, long long x_bs, float* bits_out, double* partial_ws, int N, long long CHW, void* stream);
 /* Workgroups per image of the rate kernels (a function of C*HW only, so sums are batch-invariant). */
 int dcvic_rate_blocks(long long CHW);
 /* EntropyBottleneck eval forward (entropy_bottleneck.py:19-28 -> CompressAI, App-B):

@@ -53,3 +53,24 @@ def test_cli_compress_decompress(tmp_path):
     m = build_comp_model(opt); load_synth_weights(m, 1234); m.codec_setup()
     _, _, _, u8 = m.decompress_batch([load_byte_strings(str(save_dir / "c_same.bin"))], want_u8=True)
     assert np.array_equal(u8[0].cpu().numpy(), np.asarray(Image.open(save_dir / "c_same.png")))
+
+
+def test_binary_rate_search_script(tmp_path):
+    """Caller of the batched rate path (reference scripts/binary_rate_search.py): the probed bpp is monotone in
+    beta_rate's bisection and the csv has the reference's columns."""
+    from PIL import Image
+    root, out = tmp_path / "data", tmp_path / "search"
+    root.mkdir()
+    rng = np.random.default_rng(1)
+    for i in range(3):
+        Image.fromarray(rng.integers(0, 256, (128, 128, 3), dtype=np.uint8)).save(root / f"{i}.png")
+    np.save(root / "1.npy", rng.integers(0, 256, (16, 16)).astype(np.int64))      # one item with pre-computed VQ tokens
+    cmd = [sys.executable, os.path.join(ROOT, "scripts", "binary_rate_search.py"), os.path.join(ROOT, "config", "dc_vic_synthetic.yaml"),
+           "--save_dir", str(out), "--dataset_root", str(root), "--beta_vq", "3.0", "--target_rate", "0.2", "--max_beta_rate", "3.0",
+           "--error_delta", "0.0005", "--batch_size", "2", "--synthetic_weights"]
+    subprocess.check_call(cmd, cwd=ROOT)
+    import pandas as pd
+    df = pd.read_csv(out / "result_beta_vq_3.00_target_rate_0.200.csv", index_col=0)
+    assert list(df.columns) == ["run_cnt", "beta_vq", "beta_rate", "avg_bpp", "diff"]
+    assert 1 <= len(df) <= 10 and (df["diff"].values[:-1] <= df["diff"].values[1:]).all()      # sorted by diff
+    assert (df["avg_bpp"] > 0).all() and (df["beta_rate"] >= 0).all() and (df["beta_rate"] <= 3.0).all()
