@@ -244,8 +244,11 @@ def test_vq_argmin_index_exact(dev, synth_sd):
     codebook U(+-1/256)); disagreements, if any, must be fp32 near-ties and are itemised."""
     from dc_vic_amd import ops
     from oracle import dcvic_oracle as O
-    cb = synth_sd["vq_model.quantize.embedding.weight"]
-    for seed, scale, shape in ((41, 1.0, (2, 4, 64, 64)), (42, 0.01, (3, 4, 24, 40)), (43, 3.0, (1, 4, 7, 5))):
+    cb_full = synth_sd["vq_model.quantize.embedding.weight"]
+    for seed, scale, shape, n_e in ((41, 1.0, (2, 4, 64, 64), 256), (42, 0.01, (3, 4, 24, 40), 256),
+                                    (43, 3.0, (1, 4, 7, 5), 256), (49, 0.02, (2, 4, 33, 31), 255),
+                                    (50, 0.01, (1, 4, 16, 40), 1)):
+        cb = cb_full[:n_e].contiguous()       # odd sizes exercise the packed kernel's padding code
         z = rnd(*shape, seed=seed, scale=scale)
         zq_ref, idx_ref = O.vq_quantize({"vq_model.quantize.embedding.weight": cb}, z)
         idx, zq, feat = ops.vq_argmin(z.to(dev), cb.to(dev), want_zq=True, want_feat=True)
@@ -261,7 +264,7 @@ def test_vq_argmin_index_exact(dev, synth_sd):
         assert mism.float().mean() < 1e-3
         ok = ~mism
         assert torch.equal(zq.cpu().permute(0, 2, 3, 1)[ok], zq_ref.permute(0, 2, 3, 1)[ok])
-        ref_feat = O.onehot_feat({}, zq.cpu(), idx_c)
+        ref_feat = O.onehot_feat({}, zq.cpu(), idx_c, n_embed=n_e)
         assert torch.equal(feat.cpu(), ref_feat)
 
 

@@ -27,6 +27,10 @@ def main():
     out["vq_idx_only"] = {"vectors": M, "s": t, "GBps": M * 24 / t / 1e9, "bytes_per_vector": 24}
     t = timeit(lambda: ops.vq_argmin(z, cb, want_zq=True, want_feat=False))
     out["vq_idx_zq"] = {"vectors": M, "s": t, "GBps": M * 40 / t / 1e9, "bytes_per_vector": 40}
+    # product mode: index + z_q + the [z_q | one-hot] feature the ELIC encoder consumes (1040 B written per vector)
+    z16 = z[:16].contiguous(); M16 = 16 * 256 * 256
+    t = timeit(lambda: ops.vq_argmin(z16, cb, want_zq=True, want_feat=True))
+    out["vq_idx_zq_onehot"] = {"vectors": M16, "s": t, "GBps": M16 * 1080 / t / 1e9, "bytes_per_vector": 1080}
     # rate: 2^24 elements, 16 B/element in (y, mu, sigma) + 4 out (y_hat) ... symbols+indexes+likelihood = 28 B
     y = torch.randn((64, 64, 64, 64), generator=g).to(dev) * 2
     mu = torch.randn((64, 64, 64, 64), generator=g).to(dev)
