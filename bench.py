@@ -139,6 +139,28 @@ def main():
     if ev and rank == 0 and os.environ.get("DCVIC_BENCH_DETAIL"):
         print(ops.shape_stats_report(), file=sys.stderr, flush=True)
 
+    # per-stage wall clock, from ONE extra instrumented step outside the timed region (a device sync at
+    # every stage boundary, so the stages add up to a little more than a pipelined step)
+    stage_ms = None
+    if not a.no_kernel_events:          # every rank runs the extra step (it contains the gather); rank 0 reports
+        from dc_vic_amd import comp_model as cm
+        marks = []
+
+        def hook(name):
+            torch.cuda.synchronize(dev)
+            marks.append((name, time.perf_counter()))
+        cm.STAGE_HOOK = hook
+        try:
+            step()
+        finally:
+            cm.STAGE_HOOK = None
+        stage_ms = {}
+        for (n0, t0_), (n1, t1_) in zip(marks[:-1], marks[1:]):
+            if n1 != "begin":
+                stage_ms[n1] = stage_ms.get(n1, 0.0) + 1e3 * (t1_ - t0_)
+        stage_ms["sum"] = sum(stage_ms.values())
+    sync()
+
     if dist is not None:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -156,6 +178,7 @@ def main():
                                    "compress_batch+decompress_batch through real rANS bytes, synthetic weights",
                        "batch_per_gpu": B, "quality": a.quality, "image": "256x256", "parallelism": f"dp{world} (images sharded, RCCL all_gather of the rate table)"},
             "avg_bpp": avg_bpp,
+            "stage_ms_per_step": stage_ms,
             "avg_pred_bpp": float(table[:, 1].mean() / (256 * 256)),
             "end_to_end_frac_of_f32_mfma_peak": value / world * GFLOP_PER_IMAGE / 1e3 / PEAK_F32_MFMA_TFLOPS,
         }

@@ -45,6 +45,14 @@ SPLIT_WINDOW_SIZE = 512
 SPLIT_STRIDE = 256
 
 
+STAGE_HOOK = None     # diagnostic: callable(name) invoked at stage boundaries of compress_batch / decompress_batch
+
+
+def _mark(name: str) -> None:
+    if STAGE_HOOK is not None:
+        STAGE_HOOK(name)
+
+
 def _get(opt, key, default=None):
     try:
         return opt[key]
@@ -422,12 +430,17 @@ class HyperpriorDualCondVicModel(HyperpriorVicModel):
         beta_rate = self.selected_beta_rate[quality_ind]
         beta_vq = self.selected_beta_vq[quality_ind]
         N, _, H, W = real_images.shape
+        _mark("begin")
         x = self.img_preprocess(real_images, is_train=False)
+        _mark("preproc")
         gt_vq_latent, gt_vq_indices, feat = self.vq_encode(x, None, want_feat=True)
+        _mark("encode_nn_vqgan_vq")
         y = self.comp_encode(x, gt_vq_latent, gt_vq_indices, enc_kwargs=dict(beta_1=beta_rate, beta_2=beta_vq), feat=feat)
+        _mark("encode_nn_elic")
         e = self._entropy_encode_side(y, want_symbols=True)
         y_hat = e["y_hat"]
         maxabs = ops.absmax(y_hat)
+        _mark("entropy_model_gpu")
         thr = host_threads()
         # one D2H per array; the rANS streams are independent -> host threads
         z_sym = e["z_symbols"].reshape(N, -1).cpu().numpy()
@@ -437,10 +450,12 @@ class HyperpriorDualCondVicModel(HyperpriorVicModel):
         bits_y = e["bits_y"].cpu().numpy().astype(np.float64)
         bits_z = e["bits_z"].cpu().numpy().astype(np.float64)
         zC, zH, zW = e["z"].shape[1:]
+        _mark("symbols_d2h")
         z_strs = self.entropy_model_z.tables().encode(z_sym, self.entropy_model_z._channel_indexes(N, zH * zW), threads=thr)
         y_strs = self.entropy_model_y.tables().encode(y_sym, y_idx, threads=thr)
         hh = HeaderHandler()
         string_lists = [[hh.encode((H, W), float(maxabs_h[i]), quality_ind), z_strs[i], y_strs[i]] for i in range(N)]
+        _mark("rans_encode_cpu")
         return dict(string_lists=string_lists, z_hat=e["z_hat"], y_hat=y_hat, z_likelihood=e["z_likelihood"],
                     y_likelihood=e["y_likelihood"], vq_indices=gt_vq_indices, y=y, z=e["z"], y_symbols=e["symbols"],
                     y_indexes=e["indexes"], z_symbols=e["z_symbols"],
@@ -480,16 +495,22 @@ class HyperpriorDualCondVicModel(HyperpriorVicModel):
         padW = int(np.ceil(W / self.model_stride)) * self.model_stride
         zH, zW = padH // self.model_stride, padW // self.model_stride
         beta_rate, beta_vq = self.selected_beta_rate[q], self.selected_beta_vq[q]
+        _mark("begin")
         y_hat, z_hat = self._decompress_entropy([sl[1] for sl in string_lists], [sl[2] for sl in string_lists], zH, zW)
+        _mark("entropy_decode_rans_cpu_charm_gpu")
         w = 1.0
         if max(H, W) > SPLIT_DECODE_RESOLUTION:
             fake = self.decode_split(y_hat, w, beta_rate=beta_rate, beta_vq=beta_vq)
         else:
             fake, _ = self._decode(y_hat, w, beta_rate, beta_vq)
+        _mark("decode_nn")
         if want_u8:
             img, u8 = ops.crop_clamp(fake, H, W, want_u8=True)
+            _mark("postproc")
             return img, z_hat, y_hat, u8
-        return ops.crop_clamp(fake, H, W), z_hat, y_hat
+        out = ops.crop_clamp(fake, H, W)
+        _mark("postproc")
+        return out, z_hat, y_hat
 
     @torch.no_grad()
     def decompress(self, string_list: List) -> Tuple[Tensor, Tensor, Tensor]:

@@ -7,7 +7,12 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 template <int MODE>
 __global__ __launch_bounds__(512, 2) void k(float* out, int iters, unsigned long long* clk) {
     __shared__ float lds[12288];
-    for (int i = threadIdx.x; i < 12288; i += blockDim.x) lds[i] = (float)((i * 2654435761u) >> 8) * 1e-9f;
+    for (int i = threadIdx.x; i < 12288; i += blockDim.x) {
+        if (MODE == 2) {        // full-entropy mantissas in [-1, 1): what real activations look like to the multipliers
+            unsigned h = (i + 12288u * blockIdx.x) * 2654435761u; h ^= h >> 15; h *= 2246822519u; h ^= h >> 13; h *= 3266489917u; h ^= h >> 16;
+            lds[i] = __uint_as_float(0x3f800000u | (h >> 9)) * ((h & 1) ? 1.f : -1.f) - ((h & 1) ? 1.5f : -1.5f);
+        } else lds[i] = (float)((i * 2654435761u) >> 8) * 1e-9f;
+    }
     __syncthreads();
     f32x16 acc[4];
     for (int j = 0; j < 4; ++j) for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
@@ -17,7 +22,7 @@ __global__ __launch_bounds__(512, 2) void k(float* out, int iters, unsigned long
     for (int it = 0; it < iters; ++it) {
 #pragma unroll
         for (int s = 0; s < 36; ++s) {
-            if (MODE == 1) { a0 = p[s * 128]; a1 = p[s * 128 + 64]; b0 = p[4608 + s * 68]; b1 = p[4608 + s * 68 + 34]; }
+            if (MODE >= 1) { a0 = p[s * 128]; a1 = p[s * 128 + 64]; b0 = p[4608 + s * 68]; b1 = p[4608 + s * 68 + 34]; }
             acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0], 0, 0, 0);
             acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[1], 0, 0, 0);
             acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[2], 0, 0, 0);
@@ -35,7 +40,7 @@ template <int MODE>
 void run(const char* name, int blocks) {
     float* out; unsigned long long* clk;
     hipMalloc(&out, sizeof(float) * blocks * 512); hipMalloc(&clk, 16);
-    int iters = 400;
+    int iters = MODE == 2 ? 20000 : 400;
     k<MODE><<<blocks, 512>>>(out, 10, clk);
     hipDeviceSynchronize();
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
@@ -54,5 +59,6 @@ int main() {
     run<0>("mfma-only (registers)", 512);
     run<1>("mfma + conv-like ds_read", 512);
     run<0>("mfma-only 1 WG/CU", 256);
+    run<2>("mfma + ds_read, random mantissas, sustained ~80 ms launches", 512);
     return 0;
 }
