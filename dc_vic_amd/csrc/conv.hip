@@ -138,15 +138,17 @@ __global__ __launch_bounds__(NTHREADS, (MT * NT >= 8) ? 2 : ((MT * NT >= 4) ? 3 
                 constexpr int VPT = KC * TC / 4;   // float4 per slab
                 const float4* wsrc = reinterpret_cast<const float4*>(wbase + ((long long)chunk0 * K.T + tg) * (KC * TC));
                 float4* wdst = reinterpret_cast<float4*>(Ws);
-                if (VPT >= NTHREADS || tid < VPT) {
-                    for (int t0 = 0; t0 < nslab; t0 += 3) {
-                        float4 w[3];
-                        int tt[3];
+                // the slabs of a stage are contiguous in the packed weights and in LDS: one linear float4 copy over all
+                // 256 threads; small-accumulator variants (little MFMA work per stage to hide behind) keep more loads in flight
+                constexpr int WIF = (MT * NT <= 2) ? 8 : 3;
+                const int total = nslab * VPT;
+                for (int i0 = 0; i0 < total; i0 += WIF * NTHREADS) {
+                    float4 w[WIF];
+                    int ii[WIF];
 #pragma unroll
-                        for (int j = 0; j < 3; ++j) { tt[j] = min(t0 + j, nslab - 1); w[j] = wsrc[tt[j] * VPT + tid]; }
+                    for (int j = 0; j < WIF; ++j) { ii[j] = min(i0 + j * NTHREADS + tid, total - 1); w[j] = wsrc[ii[j]]; }
 #pragma unroll
-                        for (int j = 0; j < 3; ++j) wdst[tt[j] * VPT + tid] = w[j];
-                    }
+                    for (int j = 0; j < WIF; ++j) wdst[ii[j]] = w[j];
                 }
             }
             __syncthreads();
@@ -260,6 +262,8 @@ static inline int cfg_TC(int c) { return kClassTC[c]; }
 static int g_num_cu = 0;
 static thread_local int g_last_variant = -1;   // 9000: conv3x3_dma_kernel; else cls*1000 + P (+1 when UPS)
 static int g_use_dma = 1;   // DCVIC_CONV_DMA=0 forces the generic kernel (A/B comparisons, debugging)
+static int g_use_async = 1; // DCVIC_CONV_ASYNC=0 disables conv_async.hip
+static int g_async_fill = 2; // async twin when workgroups <= g_async_fill x CUs (DCVIC_CONV_ASYNC_FILL)
 
 static int tile_width_log(int Wout) {
     int TWlog = 5;
@@ -388,6 +392,10 @@ static void init_num_cu() {
     if (g_num_cu == 0) {
         const char* e = getenv("DCVIC_CONV_DMA");
         if (e && e[0] == '0') g_use_dma = 0;
+        e = getenv("DCVIC_CONV_ASYNC");
+        if (e && e[0] == '0') g_use_async = 0;
+        e = getenv("DCVIC_CONV_ASYNC_FILL");
+        if (e && atoi(e) > 0) g_async_fill = atoi(e);
         int dev = 0, cu = 0;
         if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cu > 0) g_num_cu = cu;
         else g_num_cu = 256;
@@ -395,6 +403,14 @@ static void init_num_cu() {
 }
 
 extern "C" int dcvic_conv_last_variant(void) { return g_last_variant; }
+
+extern "C" int dcvic_conv_set_tuning(int use_dma, int use_async, int async_fill) {
+    init_num_cu();
+    if (use_dma >= 0) g_use_dma = use_dma != 0;
+    if (use_async >= 0) g_use_async = use_async != 0;
+    if (async_fill > 0) g_async_fill = async_fill;
+    return DCVIC_OK;
+}
 
 extern "C" int dcvic_conv_select_class(const dcvic_conv_desc* d, int N, int Hout, int Wout) {
     if (!d || N <= 0 || Hout <= 0 || Wout <= 0) return DCVIC_EINVAL;
@@ -501,7 +517,8 @@ extern "C" int dcvic_conv2d_f32(const dcvic_conv_desc* d, const float* packed, c
     DCVIC_CHECK_ARG(K.plane <= MAXSLOT * NTHREADS, "conv2d: patch %dx%d exceeds staging slots", K.PH, K.PW);
     K.nslots = (K.plane + NTHREADS - 1) / NTHREADS;
     // taps per weight stage: keep the slab <= 40 KiB; several channel chunks per stage when a chunk is small
-    int TG = (40 * 1024) / (KC * TC * 4);
+    static const int tg_cap_kb = getenv("DCVIC_TG_CAP_KB") ? atoi(getenv("DCVIC_TG_CAP_KB")) : 40;
+    int TG = (tg_cap_kb * 1024) / (KC * TC * 4);
     if (TG < 1) TG = 1;
     if (TG > d->T) TG = d->T;
     K.TG = TG;
@@ -524,6 +541,11 @@ extern "C" int dcvic_conv2d_f32(const dcvic_conv_desc* d, const float* packed, c
     if (P == 256 && g_use_dma) {
         const int rc = dcvic_try_conv3x3_dma(K, io->n_src, ups, cls, st);
         if (rc <= 0) { g_last_variant = 9000; return rc; }
+    }
+    if (!ups && g_use_async && blocks <= (long long)g_async_fill * g_num_cu) {
+        // about one workgroup per CU: nothing hides the staging -> the DMA double-buffered twin (same values)
+        const int rc = dcvic_try_conv_async(K, cls, P, st);
+        if (rc <= 0) { g_last_variant = 8000 + cls * 100 + P / 32; return rc; }
     }
     g_last_variant = cls * 1000 + P + (ups ? 1 : 0);
     switch (cls * 1000 + P) {

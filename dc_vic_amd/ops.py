@@ -55,6 +55,9 @@ def conv_kernel_name(variant: int) -> str:
     """Kernel name as rocprofv3 prints it, from dcvic_conv_last_variant()."""
     if variant == 9000:
         return "conv3x3_dma_kernel(ConvKArgs)"
+    if 8000 <= variant < 9000:                       # conv_async.hip: 8000 + cls*100 + P/32
+        cls, p32 = divmod(variant - 8000, 100)
+        return f"void conv_mfma_async_kernel<{_VARIANT_TILES.get((cls, p32 * 32), '?')}>(ConvKArgs, int, int)"
     cls, rest = divmod(variant, 1000)
     P, ups = rest - (rest & 1), rest & 1
     return f"void conv_mfma_kernel<{_VARIANT_TILES.get((cls, P), '?')}, {'true' if ups else 'false'}>(ConvKArgs)"

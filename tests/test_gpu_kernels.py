@@ -361,3 +361,49 @@ def test_conv_variants_bit_identical(dev, monkeypatch):
         subprocess.check_call([sys.executable, "-c", code, p], env=env)
         gen = torch.load(p)
     assert torch.equal(gen, full.cpu())
+
+
+def test_conv_async_twin_bit_identical(dev):
+    """conv_async.hip (LDS-DMA double-buffered twin used for small grids) against conv_mfma_kernel on every layer
+    geometry it can meet: 5x5, the 3x3 order family, multi-chunk 1x1 stages, stride 2, transposed-conv phases,
+    ragged channels, several sources, init accumulators, residual + affine epilogue.  Bit-identical."""
+    from dc_vic_amd import ops
+    from dc_vic_amd._lib import lib
+    L = lib()
+    cases = [  # (Cin list, Cout, k, stride, kind, H, W, N)
+        ([224], 128, 5, 1, "conv", 16, 16, 4),
+        ([128], 32, 3, 1, "conv", 16, 16, 4),
+        ([96], 96, 3, 1, "conv", 16, 16, 3),
+        ([192], 96, 1, 1, "conv", 16, 16, 4),
+        ([320], 256, 5, 2, "conv", 16, 16, 2),
+        ([192], 192, 5, 2, "convT", 4, 4, 3),
+        ([192], 256, 3, 1, "convT", 8, 8, 2),
+        ([128, 32, 64], 224, 5, 1, "conv", 16, 16, 2),
+        ([100], 77, 3, 1, "conv", 13, 11, 2),
+        ([512], 128, 1, 1, "conv", 32, 32, 1),
+        ([3], 192, 5, 2, "conv", 32, 32, 1),
+    ]
+    try:
+        for ci, (cins, cout, k, stride, kind, H, W, N) in enumerate(cases):
+            cin = sum(cins)
+            srcs = [rnd(N, c, H, W, seed=900 + 10 * ci + j).to(dev) for j, c in enumerate(cins)]
+            wshape = (cin, cout, k, k) if kind == "convT" else (cout, cin, k, k)
+            w = rnd(*wshape, seed=950 + ci, scale=(cin * k * k) ** -0.5).to(dev)
+            b = rnd(cout, seed=960 + ci, scale=0.1).to(dev)
+            plan = ops.ConvPlan(w, b, kind, stride=stride, pad=(k // 2, k // 2))
+            outs = {}
+            for mode, (use_async, fill) in {"generic": (0, 2), "async": (1, 1 << 20)}.items():
+                L.dcvic_conv_set_tuning(-1, use_async, fill)
+                y0 = plan(srcs)
+                v0 = int(L.dcvic_conv_last_variant())
+                res = rnd(*y0.shape, seed=970 + ci).to(dev)
+                aff = (rnd(N, cout, seed=980 + ci, scale=0.2).to(dev), rnd(N, cout, seed=990 + ci, scale=0.2).to(dev))
+                y1 = plan(srcs, act=ops.ACT_RELU, res=res, affine=aff)
+                y2 = plan(srcs, init=y0, use_bias=False) if kind == "conv" else y0
+                outs[mode] = (y0, y1, y2, v0)
+            assert outs["async"][3] >= 8000 and outs["async"][3] < 9000, (ci, outs["async"][3])
+            assert outs["generic"][3] < 8000 or outs["generic"][3] == 9000, (ci, outs["generic"][3])
+            for a_, g_ in zip(outs["async"][:3], outs["generic"][:3]):
+                assert torch.equal(a_, g_), f"case {ci}: async twin differs from the generic kernel"
+    finally:
+        L.dcvic_conv_set_tuning(-1, 1, 2)

@@ -36,6 +36,37 @@ __global__ __launch_bounds__(512, 2) void k(float* out, int iters, unsigned long
     if (threadIdx.x == 0 && blockIdx.x == 0) { clk[0] = t1 - t0; clk[1] = r1 - r0; }
 }
 
+// single dependent accumulator chain, NW waves per workgroup (1 or 2 per SIMD) -- what a 32x32-per-wave conv tile does
+template <int NACC>
+__global__ void kchain(float* out, int iters) {
+    f32x16 acc[NACC];
+    for (int j = 0; j < NACC; ++j) for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+    float a0 = threadIdx.x * 1e-3f, b0 = a0 * 0.5f;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int s = 0; s < 32; ++s)
+#pragma unroll
+            for (int j = 0; j < NACC; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[j], 0, 0, 0);
+    }
+    float s = 0;
+    for (int j = 0; j < NACC; ++j) for (int r = 0; r < 16; ++r) s += acc[j][r];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+template <int NACC>
+void runchain(int threads) {
+    float* out; hipMalloc(&out, sizeof(float) * 256 * threads);
+    int iters = 2000;
+    kchain<NACC><<<256, threads>>>(out, 10);
+    hipDeviceSynchronize();
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    hipEventRecord(e0);
+    kchain<NACC><<<256, threads>>>(out, iters);
+    hipEventRecord(e1); hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1);
+    double flops = 256.0 * (threads / 64) * iters * 32 * NACC * 4096.0;
+    printf("dependent chain: %d acc/wave, %d waves/CU: %.3f ms  %.1f TFLOP/s\n", NACC, threads / 64, ms, flops / ms * 1e-9);
+}
+
 template <int MODE>
 void run(const char* name, int blocks) {
     float* out; unsigned long long* clk;
@@ -56,6 +87,7 @@ void run(const char* name, int blocks) {
     }
 }
 int main() {
+    runchain<1>(256); runchain<2>(256); runchain<4>(256); runchain<1>(512); runchain<2>(512); runchain<1>(1024);
     run<0>("mfma-only (registers)", 512);
     run<1>("mfma + conv-like ds_read", 512);
     run<0>("mfma-only 1 WG/CU", 256);
