@@ -542,6 +542,11 @@ extern "C" int dcvic_conv2d_f32(const dcvic_conv_desc* d, const float* packed, c
         const int rc = dcvic_try_conv3x3_dma(K, io->n_src, ups, cls, st);
         if (rc <= 0) { g_last_variant = 9000; return rc; }
     }
+    if (g_use_dma && d->T == 1) {
+        // 1x1: flat 256-pixel tiles, DMA-pipelined GEMM (needs about a workgroup per CU to pay off)
+        const int rc = dcvic_try_conv1x1_dma(K, io->n_src, ups, cls, g_num_cu, st);
+        if (rc <= 0) { g_last_variant = 7000 + cls; return rc; }
+    }
     if (!ups && g_use_async && blocks <= (long long)g_async_fill * g_num_cu) {
         // about one workgroup per CU: nothing hides the staging -> the DMA double-buffered twin (same values)
         const int rc = dcvic_try_conv_async(K, cls, P, st);

@@ -1,0 +1,192 @@
+// conv1x1.hip -- 1x1 / stride-1 convolutions (attention q/k/v/proj, nin_shortcut, ELIC bottleneck ends, Swin
+// MLP-side projections: ~10 % of the path's time) as a DMA-pipelined GEMM  Out[co][p] = sum_ci W[co][ci] X[ci][p].
+//
+// A 1x1 convolution needs no spatial tiling: a workgroup takes 256 CONSECUTIVE pixels of the flattened H*W plane, so
+// every input-channel row of its tile is one contiguous 1 KiB segment -- exactly one `global_load_lds_dwordx4` per
+// wave (64 lanes x 16 B) straight into LDS, no VGPR staging, no per-element address arithmetic.  Stages of 16 input
+// channels (16 KiB of pixels + 16 x TC weights) are double buffered; 512 threads = 8 waves; one barrier per stage.
+// Same packed-weight layout ([cotile][chunk][tap = 1][8][TC]), reduction order (channel ascending, in MFMA k-pairs)
+// and epilogue as conv.hip: results are bit-identical to the generic kernel.
+#include "conv_common.h"
+
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+
+static __device__ __attribute__((aligned(16))) float dcvic_zero_row[4];   // source of out-of-range 16-B groups
+
+#define Q_P 256          /* pixels per workgroup */
+#define Q_CH 16          /* input channels per stage */
+#define Q_THREADS 512
+
+// TCv = 128: waves 2 x 4, each 64 ch x 64 px (MT = NT = 2);  96 / 64: waves 1 x 8, each TCv ch x 32 px (MT = 3 / 2, NT = 1)
+template <int TCv>
+__global__ __launch_bounds__(Q_THREADS, 2) void conv1x1_dma_kernel(const ConvKArgs K) {
+    constexpr int WM = (TCv == 128) ? 2 : 1;
+    constexpr int WN = 8 / WM;
+    constexpr int MT = TCv / (32 * WM);
+    constexpr int NT = Q_P / (32 * WN);
+    constexpr int XS = Q_CH * Q_P;                 // floats
+    constexpr int WS = Q_CH * TCv;
+    constexpr int BUF = XS + WS;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int lane_k = lane >> 5, lane_j = lane & 31;
+
+    int b;
+    {
+        const int orig = blockIdx.x, nb = K.nblocks;
+        const int q = nb / NXCD, r = nb % NXCD, x = orig % NXCD;
+        b = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + orig / NXCD;
+    }
+    const int cotile = b % K.n_cotiles; b /= K.n_cotiles;
+    const int ptile = b % K.tiles_x; b /= K.tiles_x;
+    const int n = b;
+    const int HW = K.H * K.W;
+    const int p0 = ptile * Q_P;
+
+    f32x16 acc[MT][NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const float* wbase = K.wp + (long long)cotile * K.n_chunks * (long long)(KC * TCv);
+    const int n_stages = (K.n_chunks * KC + Q_CH - 1) / Q_CH;
+    // this lane's 16-B group of a channel row; groups past the end of the plane read zeros (HW % 4 == 0)
+    const int pl = p0 + lane * 4;
+    const bool pin = pl < HW;
+
+    auto issue = [&](int stage, int buf) {
+        float* xb = smem + buf * BUF;
+        float* wb = xb + XS;
+        // pixel rows: wave w moves channels w and w + 8 of the stage
+#pragma unroll
+        for (int j = 0; j < Q_CH / 8; ++j) {
+            const int kk = wave + 8 * j;
+            int c = stage * Q_CH + kk;
+            const float* gp = dcvic_zero_row;
+            if (pin && c < K.Cin) {
+                int si = 0;
+                if (c >= K.srcC[0]) { c -= K.srcC[0]; si = 1; if (c >= K.srcC[1]) { c -= K.srcC[1]; si = 2; } }
+                gp = K.src[si] + (long long)n * K.src_bs[si] + (long long)c * HW + pl;
+            }
+            __builtin_amdgcn_global_load_lds(gp, (lds_ptr_t)(xb + kk * Q_P), 16, 0, 0);
+        }
+        // weight rows: Q_CH x TCv floats, contiguous in the pack (two chunks); chunks past the end are zero-filled by the pack
+        const int chunk0 = stage * (Q_CH / KC);
+        const int nfl = min(Q_CH / KC, K.n_chunks - chunk0) * (KC * TCv);           // floats available
+        const float4* w4 = reinterpret_cast<const float4*>(wbase + (long long)chunk0 * (KC * TCv));
+        constexpr int NV = WS / 4;                                                  // float4 per stage
+#pragma unroll
+        for (int j = 0; j < (NV + Q_THREADS - 1) / Q_THREADS; ++j) {
+            const int v0 = j * Q_THREADS + wave * 64;                                // wave-uniform
+            if (v0 < NV) {
+                const float4* gp4 = (v0 * 4 < nfl) ? (w4 + v0 + lane) : reinterpret_cast<const float4*>(dcvic_zero_row);
+                __builtin_amdgcn_global_load_lds(gp4, (lds_ptr_t)(wb + v0 * 4), 16, 0, 0);
+            }
+        }
+    };
+
+    issue(0, 0);
+    __syncthreads();
+
+    const int alane = lane_k * TCv + wm * (MT * 32) + lane_j;
+    const int xlane = lane_k * Q_P + wn * (NT * 32) + lane_j;
+    for (int stage = 0; stage < n_stages; ++stage) {
+        const int buf = stage & 1;
+        if (stage + 1 < n_stages) issue(stage + 1, buf ^ 1);
+        const float* xb = smem + buf * BUF + xlane;
+        const float* wb = smem + buf * BUF + XS + alane;
+        float a_cur[MT], b_cur[NT], a_nxt[MT], b_nxt[NT];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) a_cur[mt] = wb[mt * 32];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) b_cur[nt] = xb[nt * 32];
+#pragma unroll
+        for (int ks = 0; ks < Q_CH / 2; ++ks) {
+            if (ks + 1 < Q_CH / 2) {
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) a_nxt[mt] = wb[(2 * (ks + 1)) * TCv + mt * 32];
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) b_nxt[nt] = xb[(2 * (ks + 1)) * Q_P + nt * 32];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[mt], b_cur[nt], acc[mt][nt], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < MT; ++i) a_cur[i] = a_nxt[i];
+#pragma unroll
+            for (int i = 0; i < NT; ++i) b_cur[i] = b_nxt[i];
+        }
+        __syncthreads();
+    }
+
+    // ---- epilogue: bias -> act -> (+res) -> (affine) -> store  (same order as conv.hip); output plane is flat
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const int pix = p0 + wn * (NT * 32) + nt * 32 + lane_j;
+        if (pix >= HW) continue;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = cotile * TCv + (wm * MT + mt) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lane_k;
+                if (co >= K.Cout) continue;
+                float v = acc[mt][nt][r];
+                if (K.bias) v += K.bias[co];
+                v = dcvic_act(v, K.act);
+                if (K.res) v += K.res[(long long)n * K.res_bs + (long long)co * HW + pix];
+                if (K.affs) {
+                    const long long ai = (long long)n * K.aff_bs + co;
+                    v = v * (1.f + K.affs[ai]) + K.afft[ai];
+                }
+                K.out[(long long)n * K.out_bs + (long long)co * HW + pix] = v;
+            }
+        }
+    }
+}
+
+template <int TCv>
+static int launch_1x1(const ConvKArgs& A, hipStream_t st) {
+    static bool attr_set = false;
+    auto k = conv1x1_dma_kernel<TCv>;
+    if (!attr_set) {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set = true;
+    }
+    const size_t lds = (size_t)2 * (Q_CH * Q_P + Q_CH * TCv) * sizeof(float);
+    k<<<A.nblocks, Q_THREADS, lds, st>>>(A);
+    DCVIC_CHECK_LAUNCH("conv1x1_dma");
+    return DCVIC_OK;
+}
+
+// returns DCVIC_OK after launching, 1 when the launch is not eligible (caller falls back to conv_mfma_kernel)
+int dcvic_try_conv1x1_dma(const ConvKArgs& K, int n_src, bool upsample, int cls, int min_blocks, hipStream_t st) {
+    if (K.T != 1 || K.stride != 1 || upsample || K.init || K.dy0 != 0 || K.dx0 != 0) return 1;
+    if (K.osy != 1 || K.osx != 1 || K.ooy != 0 || K.oox != 0) return 1;
+    if (K.Hout != K.H || K.Wout != K.W || K.Hfull != K.H || K.Wfull != K.W) return 1;
+    const long long HW = (long long)K.H * K.W;
+    if ((HW & 3) || HW >= (1ll << 30)) return 1;
+    for (int i = 0; i < n_src; ++i)
+        if ((K.src_bs[i] & 3) || (reinterpret_cast<uintptr_t>(K.src[i]) & 15)) return 1;
+    if (cls != 0 && cls != 1 && cls != 3) return 1;
+    ConvKArgs A = K;
+    A.tiles_x = (int)((HW + Q_P - 1) / Q_P);
+    A.tiles_y = 1;
+    const long long blocks = (long long)K.N * A.tiles_x * K.n_cotiles;
+    if (blocks >= (1ll << 31) || blocks < min_blocks) return 1;
+    A.nblocks = (int)blocks;
+    switch (cls) {
+        case 0: return launch_1x1<128>(A, st);
+        case 1: return launch_1x1<64>(A, st);
+        default: return launch_1x1<96>(A, st);
+    }
+}

@@ -362,9 +362,25 @@ static int launch_async(const ConvKArgs& K, int xs_floats, int ws_floats, hipStr
 }
 
 // returns DCVIC_OK after launching, 1 when the launch is not eligible (caller falls back to conv_mfma_kernel)
-int dcvic_try_conv_async(const ConvKArgs& K, int cls, int P, hipStream_t st) {
+int dcvic_try_conv_async(const ConvKArgs& Kin, int cls, int P, hipStream_t st) {
     static const int TCs[4] = {128, 64, 32, 96};
+    static const int stage_kb = getenv("DCVIC_ASYNC_STAGE_KB") ? atoi(getenv("DCVIC_ASYNC_STAGE_KB")) : 40;
     const int TC = TCs[cls];
+    ConvKArgs K = Kin;
+    // Own stage partition (the reduction order does not depend on it): small stages keep a workgroup near 50 KiB of LDS
+    // so that two or three of them -- e.g. the two CHARM parameter networks launched on two streams -- share a CU and
+    // every SIMD has more than one independent MFMA chain to interleave.  The 3x3 family keeps whole taps per stage.
+    int TG = (stage_kb * 1024) / (KC * TC * 4);
+    if (TG < 1) TG = 1;
+    if (K.halves == 2 && TG < K.T) TG = K.T;
+    if (TG > K.T) TG = K.T;
+    int CPS = 1;
+    if (TG == K.T) {
+        const int per_chunk = (KC * K.plane + K.T * KC * TC) * 4;
+        while (CPS < 8 && (CPS + 1) * per_chunk <= stage_kb * 1024 + 8 * 1024 && (CPS + 1) * KC * K.plane <= A_MAXSLOT * NTHREADS) ++CPS;
+        if (CPS > K.n_chunks) CPS = K.n_chunks;
+    }
+    K.TG = TG; K.CPS = CPS;
     const int stage_elems = K.CPS * KC * K.plane;
     const int xslots = (stage_elems + NTHREADS - 1) / NTHREADS;
     if (xslots > A_MAXSLOT) return 1;
@@ -375,12 +391,15 @@ int dcvic_try_conv_async(const ConvKArgs& K, int cls, int P, hipStream_t st) {
     const int ws_floats = (slabs + 2) * KC * TC;
     if ((size_t)2 * (xs_floats + ws_floats) * sizeof(float) > 156 * 1024) return 1;
     switch (cls * 1000 + P) {
+        case 0 * 1000 + 256: return launch_async<2, 4, 2, 2>(K, xs_floats, ws_floats, st);
         case 0 * 1000 + 128: return launch_async<2, 2, 2, 2>(K, xs_floats, ws_floats, st);
         case 0 * 1000 + 64: return launch_async<2, 1, 2, 2>(K, xs_floats, ws_floats, st);
+        case 1 * 1000 + 256: return launch_async<2, 2, 1, 4>(K, xs_floats, ws_floats, st);
         case 1 * 1000 + 128: return launch_async<1, 2, 2, 2>(K, xs_floats, ws_floats, st);
         case 1 * 1000 + 64: return launch_async<1, 1, 2, 2>(K, xs_floats, ws_floats, st);
         case 2 * 1000 + 256: return launch_async<1, 2, 1, 4>(K, xs_floats, ws_floats, st);
         case 2 * 1000 + 128: return launch_async<1, 1, 1, 4>(K, xs_floats, ws_floats, st);
+        case 3 * 1000 + 256: return launch_async<3, 2, 1, 4>(K, xs_floats, ws_floats, st);
         case 3 * 1000 + 128: return launch_async<3, 1, 1, 4>(K, xs_floats, ws_floats, st);
         default: return 1;
     }

@@ -55,6 +55,8 @@ def conv_kernel_name(variant: int) -> str:
     """Kernel name as rocprofv3 prints it, from dcvic_conv_last_variant()."""
     if variant == 9000:
         return "conv3x3_dma_kernel(ConvKArgs)"
+    if 7000 <= variant < 8000:                       # conv1x1.hip: 7000 + cls
+        return f"void conv1x1_dma_kernel<{(128, 64, 32, 96)[variant - 7000]}>(ConvKArgs)"
     if 8000 <= variant < 9000:                       # conv_async.hip: 8000 + cls*100 + P/32
         cls, p32 = divmod(variant - 8000, 100)
         return f"void conv_mfma_async_kernel<{_VARIANT_TILES.get((cls, p32 * 32), '?')}>(ConvKArgs, int, int)"

@@ -407,3 +407,44 @@ def test_conv_async_twin_bit_identical(dev):
                 assert torch.equal(a_, g_), f"case {ci}: async twin differs from the generic kernel"
     finally:
         L.dcvic_conv_set_tuning(-1, 1, 2)
+
+
+def test_conv1x1_dma_bit_identical(dev):
+    """conv1x1_dma_kernel (flat-pixel DMA-pipelined GEMM) against the generic kernel: all three channel-tile classes,
+    odd chunk counts, channels not a multiple of 8, several sources, ragged plane (H*W % 256 != 0), residual +
+    affine epilogue, and the ineligible case (H*W % 4 != 0) falling back."""
+    from dc_vic_amd import ops
+    from dc_vic_amd._lib import lib
+    L = lib()
+    cases = [  # (Cin list, Cout, H, W, N, expect_dma)
+        ([512], 1536, 32, 32, 8, True),
+        ([96], 192, 64, 64, 10, True),
+        ([192], 96, 64, 64, 20, True),
+        ([200], 128, 36, 52, 36, True),          # 25 chunks (odd), ragged plane 1872 = 7.3 tiles
+        ([128, 64, 60], 64, 40, 40, 40, True),   # three sources, Cin 252 not a multiple of 8, class 1
+        ([64], 128, 15, 15, 40, False),          # H*W = 225 not a multiple of 4 -> generic
+    ]
+    try:
+        for ci, (cins, cout, H, W, N, expect) in enumerate(cases):
+            cin = sum(cins)
+            srcs = [rnd(N, c, H, W, seed=1200 + 10 * ci + j).to(dev) for j, c in enumerate(cins)]
+            w = rnd(cout, cin, 1, 1, seed=1250 + ci, scale=cin ** -0.5).to(dev)
+            b = rnd(cout, seed=1260 + ci, scale=0.1).to(dev)
+            plan = ops.ConvPlan(w, b, "conv")
+            res = rnd(N, cout, H, W, seed=1270 + ci).to(dev)
+            aff = (rnd(N, cout, seed=1280 + ci, scale=0.2).to(dev), rnd(N, cout, seed=1290 + ci, scale=0.2).to(dev))
+            outs = {}
+            for mode, use_dma in (("generic", 0), ("dma", 1)):
+                L.dcvic_conv_set_tuning(use_dma, 0, -1)
+                y0 = plan(srcs)
+                v0 = int(L.dcvic_conv_last_variant())
+                y1 = plan(srcs, act=ops.ACT_GELU, res=res, affine=aff)
+                outs[mode] = (y0, y1, v0)
+            assert (7000 <= outs["dma"][2] < 8000) == expect, (ci, outs["dma"][2])
+            assert outs["generic"][2] < 7000, (ci, outs["generic"][2])
+            assert torch.equal(outs["dma"][0], outs["generic"][0]), f"case {ci}"
+            assert torch.equal(outs["dma"][1], outs["generic"][1]), f"case {ci} (epilogue)"
+            ref = torch.nn.functional.conv2d(torch.cat(srcs, 1).cpu(), w.cpu(), b.cpu())
+            close(outs["dma"][0], ref, rtol=2e-5, atol=2e-5)
+    finally:
+        L.dcvic_conv_set_tuning(1, 1, 2)
