@@ -539,15 +539,17 @@ extern "C" int dcvic_conv2d_f32(const dcvic_conv_desc* d, const float* packed, c
     hipStream_t st = (hipStream_t)stream;
     const bool ups = d->upsample != 0;
     if (P == 256 && g_use_dma) {
-        const int rc = dcvic_try_conv3x3_dma(K, io->n_src, ups, cls, st);
-        if (rc <= 0) { g_last_variant = 9000; return rc; }
+        int var = 9000;
+        const int rc = dcvic_try_conv3x3_dma(K, io->n_src, ups, cls, st, &var);
+        if (rc <= 0) { g_last_variant = var; return rc; }
     }
     if (g_use_dma && d->T == 1) {
         // 1x1: flat 256-pixel tiles, DMA-pipelined GEMM (needs about a workgroup per CU to pay off)
         const int rc = dcvic_try_conv1x1_dma(K, io->n_src, ups, cls, g_num_cu, st);
         if (rc <= 0) { g_last_variant = 7000 + cls; return rc; }
     }
-    if (!ups && g_use_async && blocks <= (long long)g_async_fill * g_num_cu) {
+    // measured: the async twin wins with about one workgroup per CU, and up to g_async_fill per CU for the small tiles
+    if (!ups && g_use_async && blocks <= (long long)(P == 256 ? 1 : g_async_fill) * g_num_cu) {
         // about one workgroup per CU: nothing hides the staging -> the DMA double-buffered twin (same values)
         const int rc = dcvic_try_conv_async(K, cls, P, st);
         if (rc <= 0) { g_last_variant = 8000 + cls * 100 + P / 32; return rc; }

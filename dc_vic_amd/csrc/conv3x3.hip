@@ -14,6 +14,10 @@
 //     workgroup's barrier / DMA issue hides behind the others' MFMAs;
 //   * tap and channel offsets are compile-time immediates of ds_read_b32 -- no address VALU in the loop.
 // LDS: 2 x (1536 + 4608) floats = 48 KiB per workgroup.
+//
+// The kernel is a template over the tap grid: <3,3,4> is the 3x3/stride-1/pad-1 family (4-channel stages, the order
+// (chunk, half, tap, channel) that conv.hip mirrors for K.halves == 2); <2,2,8> runs the 2x2 sub-pixel phases of
+// "nearest x2 upsample + conv3x3" (8-channel stages, the generic (chunk, tap, channel) order).
 #include "conv_common.h"
 
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
@@ -23,17 +27,20 @@ __device__ float dcvic_zero_word[16];   // zero-initialised: source of padded la
 #define D_TC 128
 #define D_TW 32
 #define D_TH 8
-#define D_PW 34
-#define D_PLANE 340
-#define D_SKC 4                           /* channels per pipeline stage (half a packed chunk) */
 #define D_THREADS 512
-#define D_SLOTS 3                         /* ceil(D_SKC * D_PLANE / D_THREADS) */
-#define D_XS (D_SLOTS * D_THREADS)        /* 1536 floats (1360 used) */
-#define D_WS (9 * D_SKC * D_TC)           /* 4608 floats */
-#define D_BUF (D_XS + D_WS)
-#define D_CHUNK_W (9 * KC * D_TC)         /* floats of one packed 8-channel chunk */
 
+template <int TY, int TX, int SKC>
 __global__ __launch_bounds__(D_THREADS, 2) void conv3x3_dma_kernel(const ConvKArgs K) {
+    constexpr int T = TY * TX;
+    constexpr int D_PW = D_TW + TX - 1;
+    constexpr int D_PLANE = (D_TH + TY - 1) * D_PW;
+    constexpr int D_SKC = SKC;                                  // channels per pipeline stage
+    constexpr int D_SLOTS = (D_SKC * D_PLANE + D_THREADS - 1) / D_THREADS;
+    constexpr int D_XS = D_SLOTS * D_THREADS;
+    constexpr int D_WS = T * D_SKC * D_TC;
+    constexpr int D_BUF = D_XS + D_WS;
+    constexpr int D_CHUNK_W = T * KC * D_TC;                    // floats of one packed 8-channel chunk
+    constexpr int NV = T * D_SKC * (D_TC / 4);                  // float4 of weights per stage
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -52,7 +59,7 @@ __global__ __launch_bounds__(D_THREADS, 2) void conv3x3_dma_kernel(const ConvKAr
     const int tile_y = b % K.tiles_y; b /= K.tiles_y;
     const int n = b;
     const int oy0 = tile_y * D_TH, ox0 = tile_x * D_TW;
-    const int iy0 = oy0 - 1, ix0 = ox0 - 1;
+    const int iy0 = oy0 + K.dy0, ix0 = ox0 + K.dx0;
     const long long HW = (long long)K.H * K.W;
 
     // per-slot source offsets of the patch elements this thread moves (identical for every chunk)
@@ -92,14 +99,14 @@ __global__ __launch_bounds__(D_THREADS, 2) void conv3x3_dma_kernel(const ConvKAr
             const float* gp = poff[s] >= 0 ? base + poff[s] : dcvic_zero_word;
             __builtin_amdgcn_global_load_lds(gp, (lds_ptr_t)(xb + wave * 64 + s * D_THREADS), 4, 0, 0);
         }
-        // weight rows of this stage: for each tap, D_SKC x 128 floats = 128 float4 at (tap*8 + half*4)*128 of the chunk
-        const int chunk = stage / (KC / D_SKC), half = stage % (KC / D_SKC);
-        const float4* w4 = reinterpret_cast<const float4*>(wbase + (long long)chunk * D_CHUNK_W) + half * (D_SKC * D_TC / 4);
+        // weight rows of this stage: for each tap, D_SKC x 128 floats at (tap*8 + sub*D_SKC)*128 of the packed chunk
+        const int chunk = stage / (KC / D_SKC), sub = stage % (KC / D_SKC);
+        const float4* w4 = reinterpret_cast<const float4*>(wbase + (long long)chunk * D_CHUNK_W) + sub * (D_SKC * D_TC / 4);
 #pragma unroll
-        for (int j = 0; j < 3; ++j) {
-            const int v = tid + j * D_THREADS;           // 9 * 128 = 1152 float4 = 2.25 x 512
-            if (j < 2 || wave < 2) {
-                const int t = v >> 7, i = v & 127;
+        for (int j = 0; j < (NV + D_THREADS - 1) / D_THREADS; ++j) {
+            const int v = tid + j * D_THREADS;
+            if (j * D_THREADS + wave * 64 < NV) {                 // wave-uniform (NV is a multiple of 64)
+                const int t = v / (D_SKC * D_TC / 4), i = v % (D_SKC * D_TC / 4);
                 __builtin_amdgcn_global_load_lds(w4 + t * (KC * D_TC / 4) + i, (lds_ptr_t)(wb + (wave * 64 + j * D_THREADS) * 4), 16, 0, 0);
             }
         }
@@ -115,7 +122,7 @@ __global__ __launch_bounds__(D_THREADS, 2) void conv3x3_dma_kernel(const ConvKAr
         if (stage + 1 < n_stages) issue(stage + 1, buf ^ 1);
         const float* xb = smem + buf * D_BUF + xlane;
         const float* wb = smem + buf * D_BUF + D_XS + alane;
-        // 18 steps (9 taps x 2 channel pairs), software pipelined: the fragments of step s+1 are in flight
+        // T x SKC/2 steps (taps x channel pairs), software pipelined: the fragments of step s+1 are in flight
         // while the four MFMAs of step s issue
         float a_cur[2], b_cur[2], a_nxt[2], b_nxt[2];
 #pragma unroll
@@ -123,10 +130,10 @@ __global__ __launch_bounds__(D_THREADS, 2) void conv3x3_dma_kernel(const ConvKAr
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt) b_cur[nt] = xb[nt * D_PW];
 #pragma unroll
-        for (int step = 0; step < 9 * D_SKC / 2; ++step) {
-            if (step + 1 < 9 * D_SKC / 2) {
+        for (int step = 0; step < T * D_SKC / 2; ++step) {
+            if (step + 1 < T * D_SKC / 2) {
                 const int t = (step + 1) / (D_SKC / 2), ks = (step + 1) % (D_SKC / 2);
-                const int ky = t / 3, kx = t - 3 * ky;
+                const int ky = t / TX, kx = t - TX * ky;
 #pragma unroll
                 for (int mt = 0; mt < 2; ++mt) a_nxt[mt] = wb[(t * D_SKC + 2 * ks) * D_TC + mt * 32];
 #pragma unroll
@@ -172,23 +179,40 @@ __global__ __launch_bounds__(D_THREADS, 2) void conv3x3_dma_kernel(const ConvKAr
     }
 }
 
-int dcvic_try_conv3x3_dma(const ConvKArgs& Kin, int n_src, bool upsample, int cls, hipStream_t st) {
+template <int TY, int TX, int SKC>
+static int launch_tap_dma(const ConvKArgs& A, hipStream_t st) {
+    static bool attr_set = false;
+    auto k = conv3x3_dma_kernel<TY, TX, SKC>;
+    constexpr int PLANE = (D_TH + TY - 1) * (D_TW + TX - 1);
+    constexpr int XS = ((SKC * PLANE + D_THREADS - 1) / D_THREADS) * D_THREADS;
+    const size_t lds = (size_t)2 * (XS + TY * TX * SKC * D_TC) * sizeof(float);
+    if (!attr_set) {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set = true;
+    }
+    k<<<A.nblocks, D_THREADS, lds, st>>>(A);
+    DCVIC_CHECK_LAUNCH("conv_tap_dma");
+    return DCVIC_OK;
+}
+
+// returns DCVIC_OK (variant_out: 9000 = 3x3, 9001 = 2x2 phases) after launching, or 1 if the layer is not eligible
+int dcvic_try_conv3x3_dma(const ConvKArgs& Kin, int n_src, bool upsample, int cls, hipStream_t st, int* variant_out) {
     const ConvKArgs& K = Kin;
-    if (K.halves != 2 || upsample || cls != 0 || K.TWlog != 5 || K.init) return 1;   // halves == 2 <=> 3x3/s1/p1 family, channels % 8 == 0
+    if (upsample || cls != 0 || K.TWlog != 5 || K.init || K.stride != 1 || K.dstep != 1) return 1;
     if ((long long)K.H * K.W * KC >= (1ll << 31)) return 1;
+    const bool fam3 = K.halves == 2;                                  // 3x3/s1/p1 family, channels % 8 == 0
+    bool ph2 = !fam3 && K.T == 4 && K.TX == 2;                        // 2x2 sub-pixel phase of upsample + conv3x3
+    if (ph2) {
+        if (K.Cin % KC) ph2 = false;
+        for (int i = 0; i < n_src; ++i) if (K.srcC[i] % KC) ph2 = false;
+    }
+    if (!fam3 && !ph2) return 1;
     ConvKArgs A = K;
     A.tiles_y = (K.Hout + D_TH - 1) / D_TH;
     A.tiles_x = (K.Wout + D_TW - 1) / D_TW;
     const long long blocks = (long long)K.N * A.tiles_y * A.tiles_x * K.n_cotiles;
     if (blocks >= (1ll << 31)) return 1;
     A.nblocks = (int)blocks;
-    static bool attr_set = false;
-    const size_t lds = (size_t)2 * D_BUF * sizeof(float);
-    if (!attr_set) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_dma_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_set = true;
-    }
-    conv3x3_dma_kernel<<<A.nblocks, D_THREADS, lds, st>>>(A);
-    DCVIC_CHECK_LAUNCH("conv3x3_dma");
-    return DCVIC_OK;
+    if (variant_out) *variant_out = fam3 ? 9000 : 9001;
+    return fam3 ? launch_tap_dma<3, 3, 4>(A, st) : launch_tap_dma<2, 2, 8>(A, st);
 }

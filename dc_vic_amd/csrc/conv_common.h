@@ -38,7 +38,7 @@ struct ConvKArgs {
 
 
 // defined in conv3x3.hip: returns DCVIC_OK after launching, or 1 if the layer is not eligible
-int dcvic_try_conv3x3_dma(const ConvKArgs& K, int n_src, bool upsample, int cls, hipStream_t st);
+int dcvic_try_conv3x3_dma(const ConvKArgs& K, int n_src, bool upsample, int cls, hipStream_t st, int* variant_out);
 
 // defined in conv_async.hip: DMA double-buffered twin of conv_mfma_kernel<...,false> for small grids; same return convention
 int dcvic_try_conv_async(const ConvKArgs& K, int cls, int P, hipStream_t st);

@@ -54,7 +54,9 @@ _VARIANT_TILES = {(0, 256): "2, 4, 2, 2", (0, 128): "2, 2, 2, 2", (0, 64): "2, 1
 def conv_kernel_name(variant: int) -> str:
     """Kernel name as rocprofv3 prints it, from dcvic_conv_last_variant()."""
     if variant == 9000:
-        return "conv3x3_dma_kernel(ConvKArgs)"
+        return "void conv3x3_dma_kernel<3, 3, 4>(ConvKArgs)"
+    if variant == 9001:
+        return "void conv3x3_dma_kernel<2, 2, 8>(ConvKArgs)"
     if 7000 <= variant < 8000:                       # conv1x1.hip: 7000 + cls
         return f"void conv1x1_dma_kernel<{(128, 64, 32, 96)[variant - 7000]}>(ConvKArgs)"
     if 8000 <= variant < 9000:                       # conv_async.hip: 8000 + cls*100 + P/32

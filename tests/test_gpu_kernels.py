@@ -448,3 +448,28 @@ def test_conv1x1_dma_bit_identical(dev):
             close(outs["dma"][0], ref, rtol=2e-5, atol=2e-5)
     finally:
         L.dcvic_conv_set_tuning(1, 1, 2)
+
+
+def test_conv_upsample_phases_dma_bit_identical(dev):
+    """nearest-x2 upsample + conv3x3 runs as four 2x2 sub-pixel phases; with enough work they go to the DMA tap kernel
+    (<2,2,8>).  Same values as the generic kernel, and close to torch's upsample + conv."""
+    from dc_vic_amd import ops
+    from dc_vic_amd._lib import lib
+    L = lib()
+    x = rnd(24, 128, 64, 64, seed=1300).to(dev)
+    w = rnd(128, 128, 3, 3, seed=1301, scale=0.03).to(dev)
+    b = rnd(128, seed=1302, scale=0.1).to(dev)
+    plan = ops.ConvPlan(w, b, "conv", pad=(1, 1), upsample=True)
+    try:
+        L.dcvic_conv_set_tuning(0, 0, -1)
+        gen = plan(x)
+        vg = int(L.dcvic_conv_last_variant())
+        L.dcvic_conv_set_tuning(1, 0, -1)
+        dma = plan(x)
+        vd = int(L.dcvic_conv_last_variant())
+    finally:
+        L.dcvic_conv_set_tuning(1, 1, 2)
+    assert vd == 9001 and vg < 7000, (vd, vg)
+    assert torch.equal(gen, dma)
+    ref = torch.nn.functional.conv2d(torch.nn.functional.interpolate(x.cpu(), scale_factor=2.0, mode="nearest"), w.cpu(), b.cpu(), padding=1)
+    close(dma, ref, rtol=1e-4, atol=1e-4)
