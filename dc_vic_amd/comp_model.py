@@ -45,6 +45,64 @@ SPLIT_WINDOW_SIZE = 512
 SPLIT_STRIDE = 256
 
 
+class _GraphCache:
+    """hipGraph replay of a pure-device network segment (no host sync inside) for small batches, where a 256x256 image is
+    ~1 500 kernel launches of a few microseconds each and the Python/ctypes launcher, not the GPU, sets the latency.
+    A segment is captured once per (segment, input shapes, conditioning) on torch's capture stream -- the C-ABI kernels
+    launch on torch's current stream, so they are recorded like any other work -- and replayed afterwards; inputs are
+    copied into the graph's static buffers, outputs are the graph's static tensors (valid until the next replay).
+    Captures that fail (unsupported call inside the segment) fall back to the eager path for good."""
+
+    def __init__(self, max_entries: int = 6):
+        self.entries: "OrderedDict" = OrderedDict()
+        self.max_entries = max_entries
+        # opt-in (DCVIC_GRAPHS=1): measured on MI355X, N=1 at 256x256 is NOT launch-bound -- the ~900 kernels of a
+        # compress+decompress keep the GPU busy for 54 of 54 ms (one 32x32 MFMA chain per SIMD), so replay buys nothing
+        self.disabled = os.environ.get("DCVIC_GRAPHS", "0") != "1"
+        self.max_pixels = int(os.environ.get("DCVIC_GRAPH_MAX_PIXELS", str(1 << 20)))
+
+    def clear(self):
+        self.entries.clear()
+
+    def usable(self, n_pixels: int) -> bool:
+        return (not self.disabled) and n_pixels <= self.max_pixels and ops._EVENTS is None and STAGE_HOOK is None
+
+    def run(self, key, fn, inputs: Sequence[Tensor], keep=None):
+        ent = self.entries.get(key)
+        if ent is None:
+            static_in = [torch.empty_like(t) for t in inputs]
+            for s_, t in zip(static_in, inputs):
+                s_.copy_(t)
+            try:
+                side = torch.cuda.Stream()
+                side.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(side):          # warm-up: lazy weight packs, function attributes, caches
+                    fn(*static_in)
+                torch.cuda.current_stream().wait_stream(side)
+                graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph):
+                    out = fn(*static_in)
+            except Exception as e:                     # noqa: BLE001 -- any capture failure means "stay eager"
+                self.disabled = True
+                torch.cuda.synchronize()
+                print(f"[dc_vic_amd] hipGraph capture disabled: {type(e).__name__}: {e}", flush=True)
+                if os.environ.get("DCVIC_GRAPH_DEBUG"):
+                    import traceback
+                    traceback.print_exc()
+                return fn(*inputs)
+            ent = (graph, static_in, out, keep() if callable(keep) else keep)
+            self.entries[key] = ent
+            while len(self.entries) > self.max_entries:
+                self.entries.popitem(last=False)
+        else:
+            self.entries.move_to_end(key)
+        graph, static_in, out, _ = ent
+        for s_, t in zip(static_in, inputs):
+            s_.copy_(t)
+        graph.replay()
+        return out
+
+
 STAGE_HOOK = None     # diagnostic: callable(name) invoked at stage boundaries of compress_batch / decompress_batch
 
 
@@ -130,6 +188,7 @@ class BaseModel(nn.Module):
             raise NotImplementedError("convert_img_range_to_01 is not used by the DC-VIC configs")
         self._build_subnets()
         self.stride = 64
+        self._graphs = _GraphCache()
 
     def _build_subnets(self):
         raise NotImplementedError()
@@ -171,6 +230,7 @@ class BaseModel(nn.Module):
 
     def load_state_dict(self, state_dict, strict: bool = True):
         out = super().load_state_dict(state_dict, strict=strict)
+        self._graphs.clear()                   # captured segments hold the old packed weights
         for m in self.modules():
             if hasattr(m, "invalidate_caches"):
                 m.invalidate_caches()
@@ -431,12 +491,24 @@ class HyperpriorDualCondVicModel(HyperpriorVicModel):
         beta_vq = self.selected_beta_vq[quality_ind]
         N, _, H, W = real_images.shape
         _mark("begin")
-        x = self.img_preprocess(real_images, is_train=False)
-        _mark("preproc")
-        gt_vq_latent, gt_vq_indices, feat = self.vq_encode(x, None, want_feat=True)
-        _mark("encode_nn_vqgan_vq")
-        y = self.comp_encode(x, gt_vq_latent, gt_vq_indices, enc_kwargs=dict(beta_1=beta_rate, beta_2=beta_vq), feat=feat)
-        _mark("encode_nn_elic")
+        if self._graphs.usable(N * H * W) and max(H, W) <= SPLIT_DECODE_RESOLUTION:
+            # small batch: the encoder networks as one replayed hipGraph (launch-bound otherwise)
+            def seg(xi):
+                x_ = self.img_preprocess(xi, is_train=False)
+                lat_, idx_, feat_ = self.vq_encode(x_, None, want_feat=True)
+                y_ = self.comp_encode(x_, lat_, idx_, enc_kwargs=dict(beta_1=beta_rate, beta_2=beta_vq), feat=feat_)
+                return idx_, y_
+            gt_vq_indices, y = self._graphs.run(("enc", tuple(real_images.shape), quality_ind, float(beta_rate), float(beta_vq)), seg,
+                                                [real_images.to(self.device, dtype=torch.float32).contiguous()],
+                                                keep=lambda: list(self.encoder._vec_cache.values()))
+            gt_vq_indices, y = gt_vq_indices.clone(), y.clone()
+        else:
+            x = self.img_preprocess(real_images, is_train=False)
+            _mark("preproc")
+            gt_vq_latent, gt_vq_indices, feat = self.vq_encode(x, None, want_feat=True)
+            _mark("encode_nn_vqgan_vq")
+            y = self.comp_encode(x, gt_vq_latent, gt_vq_indices, enc_kwargs=dict(beta_1=beta_rate, beta_2=beta_vq), feat=feat)
+            _mark("encode_nn_elic")
         e = self._entropy_encode_side(y, want_symbols=True)
         y_hat = e["y_hat"]
         maxabs = ops.absmax(y_hat)
@@ -501,6 +573,10 @@ class HyperpriorDualCondVicModel(HyperpriorVicModel):
         w = 1.0
         if max(H, W) > SPLIT_DECODE_RESOLUTION:
             fake = self.decode_split(y_hat, w, beta_rate=beta_rate, beta_vq=beta_vq)
+        elif self._graphs.usable(len(string_lists) * padH * padW):
+            fake = self._graphs.run(("dec", tuple(y_hat.shape), q, float(beta_rate), float(beta_vq)),
+                                    lambda yh: self._decode(yh, w, beta_rate, beta_vq)[0], [y_hat.contiguous()],
+                                    keep=lambda: list(self.decoder._vec_cache.values()))
         else:
             fake, _ = self._decode(y_hat, w, beta_rate, beta_vq)
         _mark("decode_nn")

@@ -214,3 +214,31 @@ def test_charm_split_and_streams_bit_identical(model, monkeypatch):
     assert torch.equal(a["y_symbols"], b["y_symbols"]) and torch.equal(a["y_indexes"], b["y_indexes"])
     assert torch.equal(a["y_hat"], b["y_hat"])
     assert a["string_lists"] == b["string_lists"]
+
+
+def test_hipgraph_replay_identical_to_eager(model):
+    """Opt-in (DCVIC_GRAPHS=1): small batches replay the encoder / decoder networks as captured hipGraphs.  Same
+    kernels, same arguments: bytes and reconstructions equal the eager path's, across repeated replays and a second shape."""
+    g = model._graphs
+    was = g.disabled
+    try:
+        for shape, q in (((1, 3, 256, 256), 0), ((2, 3, 128, 192), 3)):
+            x1, x2 = img(shape, 107), img(shape, 108)
+            g.disabled = True
+            e1, e2 = model.compress_batch(x1, q), model.compress_batch(x2, q)
+            ei1 = model.decompress_batch(e1["string_lists"])[0].clone()
+            ei2 = model.decompress_batch(e2["string_lists"])[0].clone()
+            g.disabled = False
+            g.clear()
+            for _ in range(2):      # first pass captures, second replays
+                r1, r2 = model.compress_batch(x1, q), model.compress_batch(x2, q)
+                assert r1["string_lists"] == e1["string_lists"] and r2["string_lists"] == e2["string_lists"]
+                assert torch.equal(r1["y"], e1["y"]) and torch.equal(r2["vq_indices"], e2["vq_indices"])
+                i1 = model.decompress_batch(r1["string_lists"])[0].clone()
+                i2 = model.decompress_batch(r2["string_lists"])[0].clone()
+                assert torch.equal(i1, ei1) and torch.equal(i2, ei2)
+            assert not g.disabled, "hipGraph capture failed and fell back to eager"
+            kinds = sorted(k[0] for k in g.entries)
+            assert "dec" in kinds and "enc" in kinds, kinds
+    finally:
+        g.disabled = was
