@@ -264,6 +264,7 @@ static thread_local int g_last_variant = -1;   // 9000: conv3x3_dma_kernel; else
 static int g_use_dma = 1;   // DCVIC_CONV_DMA=0 forces the generic kernel (A/B comparisons, debugging)
 static int g_use_async = 1; // DCVIC_CONV_ASYNC=0 disables conv_async.hip
 static int g_async_fill = 2; // async twin when workgroups <= g_async_fill x CUs (DCVIC_CONV_ASYNC_FILL)
+static int g_use_async16 = 1; // DCVIC_CONV_ASYNC16=0: keep the 32x32x2 build of the async twin for the small tiles too
 
 static int tile_width_log(int Wout) {
     int TWlog = 5;
@@ -394,6 +395,8 @@ static void init_num_cu() {
         if (e && e[0] == '0') g_use_dma = 0;
         e = getenv("DCVIC_CONV_ASYNC");
         if (e && e[0] == '0') g_use_async = 0;
+        e = getenv("DCVIC_CONV_ASYNC16");
+        if (e && e[0] == '0') g_use_async16 = 0;
         e = getenv("DCVIC_CONV_ASYNC_FILL");
         if (e && atoi(e) > 0) g_async_fill = atoi(e);
         int dev = 0, cu = 0;
@@ -407,7 +410,7 @@ extern "C" int dcvic_conv_last_variant(void) { return g_last_variant; }
 extern "C" int dcvic_conv_set_tuning(int use_dma, int use_async, int async_fill) {
     init_num_cu();
     if (use_dma >= 0) g_use_dma = use_dma != 0;
-    if (use_async >= 0) g_use_async = use_async != 0;
+    if (use_async >= 0) { g_use_async = use_async != 0; g_use_async16 = use_async != 2; }   // 2: 32x32x2 build only
     if (async_fill > 0) g_async_fill = async_fill;
     return DCVIC_OK;
 }
@@ -551,7 +554,10 @@ extern "C" int dcvic_conv2d_f32(const dcvic_conv_desc* d, const float* packed, c
     // measured: the async twin wins with about one workgroup per CU, and up to g_async_fill per CU for the small tiles
     if (!ups && g_use_async && blocks <= (long long)(P == 256 ? 1 : g_async_fill) * g_num_cu) {
         // about one workgroup per CU: nothing hides the staging -> the DMA double-buffered twin (same values)
-        const int rc = dcvic_try_conv_async(K, cls, P, st);
+        // small tiles: the 16x16x4 build (four independent accumulator chains per wave), else the 32x32x2 one
+        int rc = g_use_async16 ? dcvic_try_conv_async16(K, cls, P, st) : 1;
+        if (rc <= 0) { g_last_variant = 8500 + cls * 100 + P / 32; return rc; }
+        rc = dcvic_try_conv_async(K, cls, P, st);
         if (rc <= 0) { g_last_variant = 8000 + cls * 100 + P / 32; return rc; }
     }
     g_last_variant = cls * 1000 + P + (ups ? 1 : 0);

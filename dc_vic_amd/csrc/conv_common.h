@@ -45,3 +45,6 @@ int dcvic_try_conv_async(const ConvKArgs& K, int cls, int P, hipStream_t st);
 
 // defined in conv1x1.hip: DMA-pipelined GEMM for 1x1 / stride-1 layers with at least min_blocks workgroups; same return convention
 int dcvic_try_conv1x1_dma(const ConvKArgs& K, int n_src, bool upsample, int cls, int min_blocks, hipStream_t st);
+
+// defined in conv_async16.hip: the async twin on v_mfma_f32_16x16x4_f32 for the small tile variants; same return convention
+int dcvic_try_conv_async16(const ConvKArgs& K, int cls, int P, hipStream_t st);

@@ -125,10 +125,10 @@ int dcvic_convT_phase_desc(dcvic_conv_desc* d, int Cin, int Cout, int k, int py,
  * Every class produces bit-identical results (same reduction order). */
 int dcvic_conv_select_class(const dcvic_conv_desc* d, int N, int Hout, int Wout);
 /* Which kernel the calling thread's last dcvic_conv2d_f32 launched (profiling aid):
- * 9000 = conv3x3_dma_kernel, 8000 + class*100 + pixels-per-tile/32 = conv_mfma_async_kernel, 7000 + class = conv1x1_dma_kernel,
+ * 9000 = conv3x3_dma_kernel, 8000 (8500 for the 16x16x4 build) + class*100 + pixels-per-tile/32 = conv_mfma_async(16)_kernel, 7000 + class = conv1x1_dma_kernel,
  * otherwise class*1000 + pixels-per-tile (+1 for the upsample loader). */
 int dcvic_conv_last_variant(void);
-/* Scheduling switches (A/B runs, tests): use_dma / use_async 0|1, async_fill = the async twin is used when a launch
+/* Scheduling switches (A/B runs, tests): use_dma 0|1, use_async 0|1|2 (2 = async twin without its 16x16x4 build), async_fill = the async twin is used when a launch
  * has <= async_fill x CUs workgroups; -1 keeps a value.  Never changes results: every kernel computes the same
  * reduction order.  Process-wide; returns DCVIC_OK. */
 int dcvic_conv_set_tuning(int use_dma, int use_async, int async_fill);

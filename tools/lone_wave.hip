@@ -73,6 +73,29 @@ __global__ __launch_bounds__(256) void k(float* out, int iters, int step) {
     out[blockIdx.x * blockDim.x + threadIdx.x] = s;
 }
 
+// LDS round trip seen by a lone wave: ds_read_b32 -> s_waitcnt lgkmcnt(0), dependent chain (address from the value read)
+__global__ __launch_bounds__(256) void klat(float* out, unsigned long long* cyc, int iters, int nreads) {
+    __shared__ float lds[16384];
+    for (int i = threadIdx.x; i < 16384; i += blockDim.x) lds[i] = 0.f;
+    __syncthreads();
+    unsigned addr = (unsigned)(uintptr_t)(lds_ptr_t)lds + 4u * (threadIdx.x & 63);
+    float acc = 0.f;
+    unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    for (int it = 0; it < iters; ++it) {
+        float v0, v1, v2, v3;
+        asm volatile("ds_read_b32 %0, %1" : "=v"(v0) : "v"(addr));
+        if (nreads > 1) asm volatile("ds_read_b32 %0, %1 offset:512" : "=v"(v1) : "v"(addr)); else v1 = 0;
+        if (nreads > 2) { asm volatile("ds_read_b32 %0, %1 offset:1024" : "=v"(v2) : "v"(addr)); asm volatile("ds_read_b32 %0, %1 offset:1536" : "=v"(v3) : "v"(addr)); } else { v2 = v3 = 0; }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        acc += v0 + v1 + v2 + v3;
+        addr += (unsigned)(int)(v0 * 4.f);       // dependent (always +0)
+    }
+    unsigned long long t1 = __builtin_amdgcn_s_memtime();
+    out[blockIdx.x * blockDim.x + threadIdx.x] = acc;
+    if (threadIdx.x == 0 && blockIdx.x == 0) cyc[0] = t1 - t0;
+}
+
 template <int MODE>
 void run(const char* name) {
     float* out; hipMalloc(&out, sizeof(float) * 256 * 256);
@@ -88,7 +111,14 @@ void run(const char* name) {
     double cyc = ms * 1e-3 * 2.4e9 / (iters * 4.0);
     printf("%-58s %.3f ms  %.1f TFLOP/s  ~%.0f cycles per chain MFMA\n", name, ms, 256.0 * 4 * n_mfma * 4096.0 / ms * 1e-9, cyc);
 }
+void runlat(int nreads, int threads) {
+    float* out; unsigned long long* cyc; hipMalloc(&out, 4 * 256 * 1024); hipMalloc(&cyc, 8);
+    klat<<<256, threads>>>(out, cyc, 2000, nreads); hipDeviceSynchronize();
+    unsigned long long h; hipMemcpy(&h, cyc, 8, hipMemcpyDeviceToHost);
+    printf("LDS round trip, %d ds_read_b32 then lgkmcnt(0), %d waves/CU: %.0f shader cycles per iteration\n", nreads, threads / 64, (double)h / 2000.0);
+}
 int main() {
+    runlat(1, 256); runlat(2, 256); runlat(4, 256); runlat(4, 1024);
     run<0>("chain only");
     run<1>("chain + asm ds_read prefetch, lgkmcnt(0) per 4");
     run<2>("chain + C++ LDS loads");
