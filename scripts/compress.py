@@ -8,7 +8,8 @@ compress.py:52-70) and same outputs: <name>.bin (codec_utils container), <name>.
 written through pandas like the reference) and _avg_bitrate.json {"avg_bpp": mean(real_bpp)}.
 
 MI355X additions (not in the reference, which is single-GPU, README.md:64-65):
-  * --batch_size B codes B same-sized images per call (one rANS stream per image);
+  * --batch_size B codes B same-sized images per call (one rANS stream per image); PNG decode / encode run on
+    --io_workers threads with pinned-memory staging, the next batch is decoded while the GPU codes the current one;
   * launched under `python -m torch.distributed.run --nproc-per-node N`, the image list is sharded
     across the N GPUs (longest-processing-time-first on padded pixel count), every rank writes its own
     .bin/.png files and the per-image rows are all-gathered over RCCL so rank 0 writes the same csv /
@@ -30,6 +31,7 @@ sys.path.append(os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 
 from dc_vic_amd import BaseConfig, build_comp_model  # noqa: E402
 from dc_vic_amd.codec_utils import load_byte_strings, save_byte_strings  # noqa: E402
+from dc_vic_amd.io_pipeline import AsyncWriter, BatchPrefetcher, encode_png_u8  # noqa: E402
 from dc_vic_amd.options import compress_arg_parser  # noqa: E402
 from dc_vic_amd.parallel import gather_rate_table, shard_indices  # noqa: E402
 
@@ -53,6 +55,7 @@ def main():
     p = compress_arg_parser()
     p.add_argument("--batch_size", type=int, default=1)
     p.add_argument("--synthetic_weights", action="store_true")
+    p.add_argument("--io_workers", type=int, default=0, help="PNG decode / encode threads (0: min(8, cores))")
     args = p.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -71,7 +74,7 @@ def main():
             dist_.init_process_group("gloo", rank=rank, world_size=world)
         dist = dist_
 
-    overrides = {k: v for k, v in vars(args).items() if k not in ("batch_size", "synthetic_weights")}
+    overrides = {k: v for k, v in vars(args).items() if k not in ("batch_size", "synthetic_weights", "io_workers")}
     overrides["device"] = device
     overrides["is_train"] = False
     opt = BaseConfig.fromfile(args.config_path, overrides)
@@ -105,10 +108,15 @@ def main():
     buckets = {}
     for i in mine:
         buckets.setdefault(sizes[i], []).append(i)
+    chunks = []
     for (H, W), idxs in buckets.items():
         for s in range(0, len(idxs), max(1, args.batch_size)):
-            chunk = idxs[s:s + max(1, args.batch_size)]
-            x = torch.cat([load_png(img_path_list[i]) for i in chunk], 0)
+            chunks.append(idxs[s:s + max(1, args.batch_size)])
+    writer = AsyncWriter(args.io_workers or None)
+    loader = BatchPrefetcher([[img_path_list[i] for i in c] for c in chunks], device, workers=args.io_workers or None)
+    try:
+        for chunk, (_, x) in zip(chunks, loader):
+            H, W = sizes[chunk[0]]
             out = model.compress_batch(x, args.quality)
             bins = []
             for j, i in enumerate(chunk):
@@ -127,7 +135,9 @@ def main():
                 _, _, _, u8 = model.decompress_batch(loaded, want_u8=True)
                 u8 = u8.cpu().numpy()
                 for j, i in enumerate(chunk):
-                    write_png(os.path.join(args.save_dir, os.path.basename(img_path_list[i])), u8[j])
+                    writer.submit(encode_png_u8, os.path.join(args.save_dir, os.path.basename(img_path_list[i])), u8[j].copy())
+    finally:
+        writer.close()
 
     # gather the per-image rows (RCCL all_gather of a small fp64 table) and write the summary on rank 0
     local = np.array([[float(i)] + rows[i] for i in sorted(rows)], dtype=np.float64).reshape(-1, 11)

@@ -164,3 +164,46 @@ def test_png_loader_matches_totensor_normalize(tmp_path):
     x = cli.load_png(p)
     ref = (torch.from_numpy(img).permute(2, 0, 1).float() / 255.0 - 0.5) / 0.5
     assert x.shape == (1, 3, 5, 7) and torch.equal(x[0], ref)
+
+
+def test_io_pipeline_prefetch_and_async_write(tmp_path):
+    """Threaded PNG front / back end: batches come out in order with the reference's pixel mapping (ToTensor +
+    Normalize(.5, .5), exactly), ragged batches are refused, written PNGs decode to the same bytes, worker errors surface."""
+    from PIL import Image
+    from dc_vic_amd.io_pipeline import AsyncWriter, BatchPrefetcher, decode_png_u8, encode_png_u8
+    rng = np.random.default_rng(1)
+    paths, imgs = [], []
+    for i in range(7):
+        a = rng.integers(0, 256, size=(9, 11, 3), dtype=np.uint8)
+        p = str(tmp_path / f"im{i:02d}.png")
+        Image.fromarray(a).save(p)
+        paths.append(p); imgs.append(a)
+    chunks = [paths[0:3], paths[3:6], paths[6:7]]
+    got = list(BatchPrefetcher(chunks, "cpu", workers=3, depth=2))
+    assert [list(c) for c, _ in got] == chunks
+    k = 0
+    for c, x in got:
+        assert x.shape == (len(c), 3, 9, 11) and x.dtype == torch.float32
+        for j in range(len(c)):
+            ref = (torch.from_numpy(imgs[k]).permute(2, 0, 1).float() / 255.0 - 0.5) / 0.5
+            assert torch.equal(x[j], ref)
+            k += 1
+    # ragged batch -> error from the iterator
+    b = str(tmp_path / "big.png")
+    Image.fromarray(rng.integers(0, 256, size=(10, 11, 3), dtype=np.uint8)).save(b)
+    with pytest.raises(ValueError):
+        list(BatchPrefetcher([[paths[0], b]], "cpu", workers=2))
+    # asynchronous writer
+    w = AsyncWriter(workers=2)
+    outs = []
+    for i, a in enumerate(imgs):
+        o = str(tmp_path / f"out{i}.png")
+        outs.append(o)
+        w.submit(encode_png_u8, o, a)
+    w.close()
+    for o, a in zip(outs, imgs):
+        assert np.array_equal(decode_png_u8(o), a)
+    w = AsyncWriter(workers=1)
+    w.submit(encode_png_u8, str(tmp_path / "no_such_dir" / "x.png"), imgs[0])
+    with pytest.raises(Exception):
+        w.close()
