@@ -207,3 +207,31 @@ def test_io_pipeline_prefetch_and_async_write(tmp_path):
     w.submit(encode_png_u8, str(tmp_path / "no_such_dir" / "x.png"), imgs[0])
     with pytest.raises(Exception):
         w.close()
+
+
+def test_calc_metrics_psnr_and_fid_patches(tmp_path):
+    """scripts/calc_metrics.py: image-averaged PSNR on [0, 255] RGB, bpp passthrough, _metrics.json, FID patch cropper."""
+    import importlib.util
+    from PIL import Image
+    spec = importlib.util.spec_from_file_location("dcvic_metrics", os.path.join(ROOT, "scripts", "calc_metrics.py"))
+    cm = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(cm)
+    rng = np.random.default_rng(2)
+    real, fake = tmp_path / "real", tmp_path / "fake"
+    real.mkdir(); fake.mkdir()
+    want = []
+    for i in range(3):
+        a = rng.integers(0, 256, size=(20, 30, 3), dtype=np.uint8)
+        b = np.clip(a.astype(np.int32) + rng.integers(-6, 7, size=a.shape), 0, 255).astype(np.uint8)
+        Image.fromarray(a).save(real / f"k{i}.png"); Image.fromarray(b).save(fake / f"k{i}.png")
+        mse = np.mean((a.astype(np.float64) - b.astype(np.float64)) ** 2)
+        want.append(10 * np.log10(255.0 ** 2 / mse))
+    (fake / "_avg_bitrate.json").write_text(json.dumps({"avg_bpp": 0.1234}))
+    out = cm.main(["--real_dir", str(real), "--fake_dir", str(fake)])
+    assert abs(out["PSNR"] - np.mean(want)) < 1e-4 and out["bpp"] == 0.1234
+    assert json.loads((fake / "_metrics.json").read_text())["PSNR"] == out["PSNR"]
+    img = rng.integers(0, 256, size=(70, 100, 3), dtype=np.uint8)
+    pt = cm.crop_hific_fid_patches(img, 32)
+    assert pt.shape == (2 * 3 + 1 * 2, 32, 32, 3)
+    assert np.array_equal(pt[0], img[:32, :32]) and np.array_equal(pt[1], img[:32, 32:64])
+    assert np.array_equal(pt[6], img[16:48, 16:48])
