@@ -121,22 +121,32 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_mfma_async_kernel(const Conv
     const int n_tgs = (K.T + K.TG - 1) / K.TG;
     const int n_stages = n_groups * n_tgs;
 
-    auto issue = [&](int stage) {
-        const int grp = stage / n_tgs, tgi = stage - grp * n_tgs;
+    // issue() runs on the lone wave's critical path (measured: 2.5k of 7.9k cycles per stage before this was trimmed), so
+    // it keeps running (group, tap-group) counters instead of dividing, per-source base pointers are formed once, and
+    // the weight slab is a plain linear copy
+    const float* nsrc[DCVIC_MAX_SRC];
+#pragma unroll
+    for (int i = 0; i < DCVIC_MAX_SRC; ++i) nsrc[i] = K.src[i] + (long long)n * K.src_bs[i];
+    const int c_s1 = K.srcC[0], c_s2 = K.srcC[0] + K.srcC[1];      // first channel of source 1 / 2 (2^30 when absent)
+    int i_grp = 0, i_tgi = 0;                                       // coordinates of the NEXT stage to issue
+    auto issue = [&]() {
+        const int grp = i_grp, tgi = i_tgi;
         const int chunk0 = grp * K.CPS, tg = tgi * K.TG;
         const int ncs = min(K.CPS, K.n_chunks - chunk0);
+        const int stage_par = (grp * n_tgs + tgi) & 1;
         if (tgi == 0) {
             float* xb = Xs0 + (grp & 1) * xs_floats;
             const int c0 = chunk0 * KC;
+            const int cmax = min(K.Cin, c0 + ncs * KC);
 #pragma unroll
             for (int s = 0; s < A_MAXSLOT; ++s) {
                 if (s < xslots) {
-                    int c = c0 + pk[s];
+                    const int c = c0 + pk[s];
                     const float* gp = dcvic_zero_pad;
-                    if (poff[s] >= 0 && c < K.Cin && pk[s] < ncs * KC) {
-                        int si = 0;
-                        if (c >= K.srcC[0]) { c -= K.srcC[0]; si = 1; if (c >= K.srcC[1]) { c -= K.srcC[1]; si = 2; } }
-                        gp = K.src[si] + (long long)n * K.src_bs[si] + (long long)c * HW + poff[s];
+                    if (poff[s] >= 0 && c < cmax) {
+                        const float* base = c < c_s1 ? nsrc[0] + (long long)c * HW
+                                                     : (c < c_s2 ? nsrc[1] + (long long)(c - c_s1) * HW : nsrc[2] + (long long)(c - c_s2) * HW);
+                        gp = base + poff[s];
                     }
                     __builtin_amdgcn_global_load_lds(gp, (lds_ptr_t)(xb + wave * 64 + s * NTHREADS), 4, 0, 0);
                 }
@@ -145,27 +155,23 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_mfma_async_kernel(const Conv
         const int ntap = min(K.TG, K.T - tg);
         const int nslab = (K.TG >= K.T) ? ncs * K.T : ntap;
         const int total = nslab * VPT;                             // float4, a multiple of 64
-        const float4* wsrc = reinterpret_cast<const float4*>(wbase + ((long long)chunk0 * K.T + tg) * (KC * TC));
-        float* wb = Ws0 + (stage & 1) * ws_floats;
-        // Every workgroup streams the SAME slab at the same moment (one workgroup per CU, all in lockstep): walking it in
-        // the same order makes all CUs hit one L2 channel at a time (measured ~1.2 TB/s chip-wide = one 64 B/clk channel
-        // per XCD).  Each workgroup therefore starts at its own 4 KiB piece and wraps around.
-        const int npiece = (total + NTHREADS - 1) / NTHREADS;
-        int piece = (int)((blockIdx.x * 5u + stage) % (unsigned)npiece);
-        for (int j = 0; j < npiece; ++j) {
-            const int i0 = piece * NTHREADS;
-            if (i0 + wave * 64 < total)
-                __builtin_amdgcn_global_load_lds(wsrc + i0 + tid, (lds_ptr_t)(wb + (i0 + wave * 64) * 4), 16, 0, 0);
-            if (++piece == npiece) piece = 0;
+        const float4* wsrc = reinterpret_cast<const float4*>(wbase + ((long long)chunk0 * K.T + tg) * (KC * TC)) + tid;
+        float* wb = Ws0 + stage_par * ws_floats + wave * 256;
+        for (int i0 = wave * 64; i0 < total; i0 += NTHREADS) {
+            __builtin_amdgcn_global_load_lds(wsrc, (lds_ptr_t)wb, 16, 0, 0);
+            wsrc += NTHREADS; wb += NTHREADS * 4;
         }
+        if (++i_tgi == n_tgs) { i_tgi = 0; ++i_grp; }
     };
 
-    issue(0);
+    issue();
     __syncthreads();
 
+    int c_grp = 0, c_tgi = 0;                                       // coordinates of the stage being computed
     for (int stage = 0; stage < n_stages; ++stage) {
-        if (stage + 1 < n_stages) issue(stage + 1);
-        const int grp = stage / n_tgs, tgi = stage - grp * n_tgs;
+        if (stage + 1 < n_stages) issue();
+        const int grp = c_grp, tgi = c_tgi;
+        if (++c_tgi == n_tgs) { c_tgi = 0; ++c_grp; }
         const int chunk0 = grp * K.CPS, tg = tgi * K.TG;
         const int ncs = min(K.CPS, K.n_chunks - chunk0);
         const int ntap = min(K.TG, K.T - tg);

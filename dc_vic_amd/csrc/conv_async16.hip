@@ -124,22 +124,32 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_mfma_async16_kernel(const Co
     const int n_tgs = (K.T + K.TG - 1) / K.TG;
     const int n_stages = n_groups * n_tgs;
 
-    auto issue = [&](int stage) {
-        const int grp = stage / n_tgs, tgi = stage - grp * n_tgs;
+    // issue() runs on the lone wave's critical path (measured: 2.5k of 7.9k cycles per stage before this was trimmed), so
+    // it keeps running (group, tap-group) counters instead of dividing, per-source base pointers are formed once, and
+    // the weight slab is a plain linear copy
+    const float* nsrc[DCVIC_MAX_SRC];
+#pragma unroll
+    for (int i = 0; i < DCVIC_MAX_SRC; ++i) nsrc[i] = K.src[i] + (long long)n * K.src_bs[i];
+    const int c_s1 = K.srcC[0], c_s2 = K.srcC[0] + K.srcC[1];      // first channel of source 1 / 2 (2^30 when absent)
+    int i_grp = 0, i_tgi = 0;                                       // coordinates of the NEXT stage to issue
+    auto issue = [&]() {
+        const int grp = i_grp, tgi = i_tgi;
         const int chunk0 = grp * K.CPS, tg = tgi * K.TG;
         const int ncs = min(K.CPS, K.n_chunks - chunk0);
+        const int stage_par = (grp * n_tgs + tgi) & 1;
         if (tgi == 0) {
             float* xb = Xs0 + (grp & 1) * xs_floats;
             const int c0 = chunk0 * KC;
+            const int cmax = min(K.Cin, c0 + ncs * KC);
 #pragma unroll
             for (int s = 0; s < A_MAXSLOT; ++s) {
                 if (s < xslots) {
-                    int c = c0 + pk[s];
+                    const int c = c0 + pk[s];
                     const float* gp = dcvic_zero_pad16;
-                    if (poff[s] >= 0 && c < K.Cin && pk[s] < ncs * KC) {
-                        int si = 0;
-                        if (c >= K.srcC[0]) { c -= K.srcC[0]; si = 1; if (c >= K.srcC[1]) { c -= K.srcC[1]; si = 2; } }
-                        gp = K.src[si] + (long long)n * K.src_bs[si] + (long long)c * HW + poff[s];
+                    if (poff[s] >= 0 && c < cmax) {
+                        const float* base = c < c_s1 ? nsrc[0] + (long long)c * HW
+                                                     : (c < c_s2 ? nsrc[1] + (long long)(c - c_s1) * HW : nsrc[2] + (long long)(c - c_s2) * HW);
+                        gp = base + poff[s];
                     }
                     __builtin_amdgcn_global_load_lds(gp, (lds_ptr_t)(xb + wave * 64 + s * NTHREADS), 4, 0, 0);
                 }
@@ -148,27 +158,23 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_mfma_async16_kernel(const Co
         const int ntap = min(K.TG, K.T - tg);
         const int nslab = (K.TG >= K.T) ? ncs * K.T : ntap;
         const int total = nslab * VPT;                             // float4, a multiple of 64
-        const float4* wsrc = reinterpret_cast<const float4*>(wbase + ((long long)chunk0 * K.T + tg) * (KC * TC));
-        float* wb = Ws0 + (stage & 1) * ws_floats;
-        // Every workgroup streams the SAME slab at the same moment (one workgroup per CU, all in lockstep): walking it in
-        // the same order makes all CUs hit one L2 channel at a time (measured ~1.2 TB/s chip-wide = one 64 B/clk channel
-        // per XCD).  Each workgroup therefore starts at its own 4 KiB piece and wraps around.
-        const int npiece = (total + NTHREADS - 1) / NTHREADS;
-        int piece = (int)((blockIdx.x * 5u + stage) % (unsigned)npiece);
-        for (int j = 0; j < npiece; ++j) {
-            const int i0 = piece * NTHREADS;
-            if (i0 + wave * 64 < total)
-                __builtin_amdgcn_global_load_lds(wsrc + i0 + tid, (lds_ptr_t)(wb + (i0 + wave * 64) * 4), 16, 0, 0);
-            if (++piece == npiece) piece = 0;
+        const float4* wsrc = reinterpret_cast<const float4*>(wbase + ((long long)chunk0 * K.T + tg) * (KC * TC)) + tid;
+        float* wb = Ws0 + stage_par * ws_floats + wave * 256;
+        for (int i0 = wave * 64; i0 < total; i0 += NTHREADS) {
+            __builtin_amdgcn_global_load_lds(wsrc, (lds_ptr_t)wb, 16, 0, 0);
+            wsrc += NTHREADS; wb += NTHREADS * 4;
         }
+        if (++i_tgi == n_tgs) { i_tgi = 0; ++i_grp; }
     };
 
-    issue(0);
+    issue();
     __syncthreads();
 
+    int c_grp = 0, c_tgi = 0;                                       // coordinates of the stage being computed
     for (int stage = 0; stage < n_stages; ++stage) {
-        if (stage + 1 < n_stages) issue(stage + 1);
-        const int grp = stage / n_tgs, tgi = stage - grp * n_tgs;
+        if (stage + 1 < n_stages) issue();
+        const int grp = c_grp, tgi = c_tgi;
+        if (++c_tgi == n_tgs) { c_tgi = 0; ++c_grp; }
         const int chunk0 = grp * K.CPS, tg = tgi * K.TG;
         const int ncs = min(K.CPS, K.n_chunks - chunk0);
         const int ntap = min(K.TG, K.T - tg);
@@ -190,6 +196,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_mfma_async16_kernel(const Co
         for (int nt = 0; nt < N16; ++nt) bvec[nt] = 4u * (unsigned)bbase[nt];
         const unsigned plane16 = 16u * (unsigned)K.plane;        // four channels, in bytes
 
+#define ASYNC_FENCE() __builtin_amdgcn_sched_barrier(0)
+#define ASYNC_WAIT_LDS() do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); ASYNC_FENCE(); } while (0)
         auto fetch = [&](float (&a)[M16], float (&bb)[N16], unsigned wtap, unsigned xtap, unsigned h) {
             const unsigned aaddr = ws_addr + wtap + h * (16u * TC) + avec;
             static16_for<0, M16>([&](auto mt_) {
@@ -207,8 +215,33 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_mfma_async16_kernel(const Co
                 for (int nt = 0; nt < N16; ++nt)
                     acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt], bb[nt], acc[mt][nt], 0, 0, 0);
         };
-#define ASYNC_FENCE() __builtin_amdgcn_sched_barrier(0)
-#define ASYNC_WAIT_LDS() do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); ASYNC_FENCE(); } while (0)
+        // one item: the Q = M16 x N16 independent MFMAs of the current operands, with the R = M16 + N16 LDS reads of the
+        // next item's operands spread between them -- a lone wave issues in order, so reads placed after the MFMAs would
+        // only start once the last MFMA has left the issue stage, and MFMAs placed after the reads would find the pipe idle
+        auto step = [&](const float (&ca)[M16], const float (&cb)[N16], float (&na)[M16], float (&nb)[N16],
+                        unsigned wtap, unsigned xtap, unsigned h) {
+            constexpr int Q = M16 * N16, R = M16 + N16;
+            const unsigned aaddr = ws_addr + wtap + h * (16u * TC) + avec;
+            unsigned baddr[N16];
+            const unsigned xb = xs_addr + xtap + h * plane16;
+#pragma unroll
+            for (int nt = 0; nt < N16; ++nt) baddr[nt] = xb + bvec[nt];
+            ASYNC_FENCE();
+            static16_for<0, Q>([&](auto q_) {
+                constexpr int q = decltype(q_)::value;
+                constexpr int mt = q / N16, nt = q % N16;
+                acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(ca[mt], cb[nt], acc[mt][nt], 0, 0, 0);
+                ASYNC_FENCE();
+                static16_for<0, R>([&](auto r_) {
+                    constexpr int r = decltype(r_)::value;
+                    if constexpr (r * Q / R == q) {
+                        if constexpr (r < M16) na[r] = lds16_read_f32<64 * r>(aaddr);
+                        else nb[r - M16] = lds16_read_f32<0>(baddr[r - M16]);
+                    }
+                });
+                ASYNC_FENCE();
+            });
+        };
         float a0[M16], b0[N16], a1[M16], b1[N16];
         for (int cs = 0; cs < ncs; ++cs) {
             const unsigned wcs = 4u * (unsigned)(cs * ntap * KC * TC), xcs = 4u * (unsigned)(cs * KC * K.plane);
@@ -225,40 +258,31 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_mfma_async16_kernel(const Co
                     wtap += 4u * (KC * TC);
                 };
                 if (H2) {
-                    // items = taps of channel group po
+                    // items = taps of channel group po; pairs of taps ping-pong between the two register sets
                     fetch(a0, b0, wtap, xtap, (unsigned)po);
-                    for (int t = 0; t < ntap; t += 2) {
+                    int t = 0;
+                    for (; t + 1 < ntap; t += 2) {
                         advance();
                         ASYNC_WAIT_LDS();
-                        fetch(a1, b1, wtap, xtap, (unsigned)po);       // tap t+1
-                        ASYNC_FENCE();
-                        mma(a0, b0);
-                        ASYNC_FENCE();
+                        step(a0, b0, a1, b1, wtap, xtap, (unsigned)po);      // computes tap t, fetches tap t+1
                         advance();
                         ASYNC_WAIT_LDS();
-                        fetch(a0, b0, wtap, xtap, (unsigned)po);       // tap t+2
-                        ASYNC_FENCE();
-                        if (t + 1 < ntap) mma(a1, b1);
-                        ASYNC_FENCE();
+                        step(a1, b1, a0, b0, wtap, xtap, (unsigned)po);      // computes tap t+1, fetches tap t+2
                     }
+                    ASYNC_WAIT_LDS();
+                    if (t < ntap) mma(a0, b0);                               // odd tap count: the last one
                 } else {
                     // items = (tap, group 0), (tap, group 1)
                     fetch(a0, b0, wtap, xtap, 0u);
                     for (int t = 0; t < ntap; ++t) {
                         ASYNC_WAIT_LDS();
-                        fetch(a1, b1, wtap, xtap, 1u);
-                        ASYNC_FENCE();
-                        mma(a0, b0);
-                        ASYNC_FENCE();
+                        step(a0, b0, a1, b1, wtap, xtap, 1u);                // computes (t, 0), fetches (t, 1)
                         advance();
                         ASYNC_WAIT_LDS();
-                        fetch(a0, b0, wtap, xtap, 0u);                 // next tap
-                        ASYNC_FENCE();
-                        mma(a1, b1);
-                        ASYNC_FENCE();
+                        step(a1, b1, a0, b0, wtap, xtap, 0u);                // computes (t, 1), fetches (t+1, 0)
                     }
+                    ASYNC_WAIT_LDS();                                        // the extra fetch: hipcc does not count asm loads
                 }
-                ASYNC_WAIT_LDS();                                      // the extra fetch: hipcc does not count asm loads
             }
         }
 #undef ASYNC_FENCE
