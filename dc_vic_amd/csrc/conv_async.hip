@@ -43,7 +43,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_mfma_async_kernel(const Conv
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int wave = tid >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // SGPR: loops and LDS-DMA destinations stay scalar
     const int wm = wave / WN, wn = wave % WN;
     const int lane_k = lane >> 5, lane_j = lane & 31;
 
