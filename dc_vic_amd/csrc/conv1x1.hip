@@ -19,7 +19,7 @@ static __device__ __attribute__((aligned(16))) float dcvic_zero_row[4];   // sou
 
 // TCv = 128: waves 2 x 4, each 64 ch x 64 px (MT = NT = 2);  96 / 64: waves 1 x 8, each TCv ch x 32 px (MT = 3 / 2, NT = 1)
 template <int TCv>
-__global__ __launch_bounds__(Q_THREADS, 2) void conv1x1_dma_kernel(const ConvKArgs K) {
+__global__ __launch_bounds__(Q_THREADS, 4) void conv1x1_dma_kernel(const ConvKArgs K) {
     constexpr int WM = (TCv == 128) ? 2 : 1;
     constexpr int WN = 8 / WM;
     constexpr int MT = TCv / (32 * WM);
@@ -130,28 +130,20 @@ __global__ __launch_bounds__(Q_THREADS, 2) void conv1x1_dma_kernel(const ConvKAr
     }
 
     // ---- epilogue: bias -> act -> (+res) -> (affine) -> store  (same order as conv.hip); output plane is flat
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
-        const int pix = p0 + wn * (NT * 32) + nt * 32 + lane_j;
-        if (pix >= HW) continue;
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int co = cotile * TCv + (wm * MT + mt) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lane_k;
-                if (co >= K.Cout) continue;
-                float v = acc[mt][nt][r];
-                if (K.bias) v += K.bias[co];
-                v = dcvic_act(v, K.act);
-                if (K.res) v += K.res[(long long)n * K.res_bs + (long long)co * HW + pix];
-                if (K.affs) {
-                    const long long ai = (long long)n * K.aff_bs + co;
-                    v = v * (1.f + K.affs[ai]) + K.afft[ai];
-                }
-                K.out[(long long)n * K.out_bs + (long long)co * HW + pix] = v;
+    dcvic_epilogue_dispatch(K, [&](auto res_, auto aff_) {
+        constexpr bool RES = decltype(res_)::value, AFF = decltype(aff_)::value;
+        dcvic_static_for<0, NT>([&](auto nt_) {
+            constexpr int nt = decltype(nt_)::value;
+            const int pix = p0 + wn * (NT * 32) + nt * 32 + lane_j;
+            if (pix < HW) {
+                dcvic_static_for<0, MT>([&](auto mt_) {
+                    constexpr int mt = decltype(mt_)::value;
+                    const int cob = cotile * TCv + (wm * MT + mt) * 32 + 4 * lane_k;
+                    dcvic_conv_epilogue<16, (AFF ? 4 : 8), RES, AFF>(K, n, acc[mt][nt], [cob](int r) { return cob + (r & 3) + 8 * (r >> 2); }, (long long)pix, (long long)HW);
+                });
             }
-        }
-    }
+        });
+    });
 }
 
 template <int TCv>

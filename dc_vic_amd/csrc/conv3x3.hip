@@ -30,7 +30,7 @@ __device__ float dcvic_zero_word[16];   // zero-initialised: source of padded la
 #define D_THREADS 512
 
 template <int TY, int TX, int SKC>
-__global__ __launch_bounds__(D_THREADS, 2) void conv3x3_dma_kernel(const ConvKArgs K) {
+__global__ __launch_bounds__(D_THREADS, 4) void conv3x3_dma_kernel(const ConvKArgs K) {
     constexpr int T = TY * TX;
     constexpr int D_PW = D_TW + TX - 1;
     constexpr int D_PLANE = (D_TH + TY - 1) * D_PW;
@@ -154,29 +154,21 @@ __global__ __launch_bounds__(D_THREADS, 2) void conv3x3_dma_kernel(const ConvKAr
 
     // ---- epilogue: bias -> act -> (+res) -> (affine) -> store  (same order as conv.hip)
     const long long HWo = (long long)K.Hfull * K.Wfull;
-#pragma unroll
-    for (int nt = 0; nt < 2; ++nt) {
-        const int oy = oy0 + wn * 2 + nt, ox = ox0 + lane_j;
-        if (oy >= K.Hout || ox >= K.Wout) continue;
-        const long long pix = (long long)(oy * K.osy + K.ooy) * K.Wfull + (ox * K.osx + K.oox);
-#pragma unroll
-        for (int mt = 0; mt < 2; ++mt) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int co = cotile * D_TC + (wm * 2 + mt) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lane_k;
-                if (co >= K.Cout) continue;
-                float v = acc[mt][nt][r];
-                if (K.bias) v += K.bias[co];
-                v = dcvic_act(v, K.act);
-                if (K.res) v += K.res[(long long)n * K.res_bs + (long long)co * HWo + pix];
-                if (K.affs) {
-                    const long long ai = (long long)n * K.aff_bs + co;
-                    v = v * (1.f + K.affs[ai]) + K.afft[ai];
-                }
-                K.out[(long long)n * K.out_bs + (long long)co * HWo + pix] = v;
+    dcvic_epilogue_dispatch(K, [&](auto res_, auto aff_) {
+        constexpr bool RES = decltype(res_)::value, AFF = decltype(aff_)::value;
+        dcvic_static_for<0, 2>([&](auto nt_) {
+            constexpr int nt = decltype(nt_)::value;
+            const int oy = oy0 + wn * 2 + nt, ox = ox0 + lane_j;
+            if (oy < K.Hout && ox < K.Wout) {
+                const long long pix = (long long)(oy * K.osy + K.ooy) * K.Wfull + (ox * K.osx + K.oox);
+                dcvic_static_for<0, 2>([&](auto mt_) {
+                    constexpr int mt = decltype(mt_)::value;
+                    const int cob = cotile * D_TC + (wm * 2 + mt) * 32 + 4 * lane_k;
+                    dcvic_conv_epilogue<16, (AFF ? 4 : 8), RES, AFF>(K, n, acc[mt][nt], [cob](int r) { return cob + (r & 3) + 8 * (r >> 2); }, pix, HWo);
+                });
             }
-        }
-    }
+        });
+    });
 }
 
 template <int TY, int TX, int SKC>

@@ -325,29 +325,21 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_mfma_async_kernel(const Conv
 
     // ---- epilogue: bias -> act -> (+res) -> (affine) -> store  (same order as conv.hip)
     const long long HWo = (long long)K.Hfull * K.Wfull;
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
-        const int oy = oy0 + pty[nt], ox = ox0 + ptx[nt];
-        if (oy >= K.Hout || ox >= K.Wout) continue;
-        const long long pix = (long long)(oy * K.osy + K.ooy) * K.Wfull + (ox * K.osx + K.oox);
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int co = cotile * TC + (wm * MT + mt) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lane_k;
-                if (co >= K.Cout) continue;
-                float v = acc[mt][nt][r];
-                if (K.bias) v += K.bias[co];
-                v = dcvic_act(v, K.act);
-                if (K.res) v += K.res[(long long)n * K.res_bs + (long long)co * HWo + pix];
-                if (K.affs) {
-                    const long long ai = (long long)n * K.aff_bs + co;
-                    v = v * (1.f + K.affs[ai]) + K.afft[ai];
-                }
-                K.out[(long long)n * K.out_bs + (long long)co * HWo + pix] = v;
+    dcvic_epilogue_dispatch(K, [&](auto res_, auto aff_) {
+        constexpr bool RES = decltype(res_)::value, AFF = decltype(aff_)::value;
+        dcvic_static_for<0, NT>([&](auto nt_) {
+            constexpr int nt = decltype(nt_)::value;
+            const int oy = oy0 + pty[nt], ox = ox0 + ptx[nt];
+            if (oy < K.Hout && ox < K.Wout) {
+                const long long pix = (long long)(oy * K.osy + K.ooy) * K.Wfull + (ox * K.osx + K.oox);
+                dcvic_static_for<0, MT>([&](auto mt_) {
+                    constexpr int mt = decltype(mt_)::value;
+                    const int cob = cotile * TC + (wm * MT + mt) * 32 + 4 * lane_k;
+                    dcvic_conv_epilogue<16, (MT * NT >= 6 ? 4 : 8), RES, AFF>(K, n, acc[mt][nt], [cob](int r) { return cob + (r & 3) + 8 * (r >> 2); }, pix, HWo);
+                });
             }
-        }
-    }
+        });
+    });
 }
 
 template <int MT, int NT, int WM, int WN>

@@ -292,29 +292,24 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_mfma_async16_kernel(const Co
 
     // ---- epilogue: bias -> act -> (+res) -> (affine) -> store  (same order as conv.hip)
     const long long HWo = (long long)K.Hfull * K.Wfull;
+    dcvic_epilogue_dispatch(K, [&](auto res_, auto aff_) {
+        constexpr bool RES = decltype(res_)::value, AFF = decltype(aff_)::value;
+        dcvic_static_for<0, N16>([&](auto nt_) {
+            constexpr int nt = decltype(nt_)::value;
+            const int oy = oy0 + pty[nt], ox = ox0 + ptx[nt];
+            if (oy < K.Hout && ox < K.Wout) {
+                const long long pix = (long long)(oy * K.osy + K.ooy) * K.Wfull + (ox * K.osx + K.oox);
+                // the M16 groups of this pixel as one batch of 4 * M16 values
+                float av[4 * M16];
 #pragma unroll
-    for (int nt = 0; nt < N16; ++nt) {
-        const int oy = oy0 + pty[nt], ox = ox0 + ptx[nt];
-        if (oy >= K.Hout || ox >= K.Wout) continue;
-        const long long pix = (long long)(oy * K.osy + K.ooy) * K.Wfull + (ox * K.osx + K.oox);
+                for (int mt = 0; mt < M16; ++mt)
 #pragma unroll
-        for (int mt = 0; mt < M16; ++mt) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int co = cotile * TC + wm * (MT * 32) + mt * 16 + 4 * lq + r;
-                if (co >= K.Cout) continue;
-                float v = acc[mt][nt][r];
-                if (K.bias) v += K.bias[co];
-                v = dcvic_act(v, K.act);
-                if (K.res) v += K.res[(long long)n * K.res_bs + (long long)co * HWo + pix];
-                if (K.affs) {
-                    const long long ai = (long long)n * K.aff_bs + co;
-                    v = v * (1.f + K.affs[ai]) + K.afft[ai];
-                }
-                K.out[(long long)n * K.out_bs + (long long)co * HWo + pix] = v;
+                    for (int r = 0; r < 4; ++r) av[mt * 4 + r] = acc[mt][nt][r];
+                const int cob = cotile * TC + wm * (MT * 32) + 4 * lq;
+                dcvic_conv_epilogue<4 * M16, (4 * M16 < 8 ? 4 * M16 : 8), RES, AFF>(K, n, av, [cob](int q) { return cob + (q >> 2) * 16 + (q & 3); }, pix, HWo);
             }
-        }
-    }
+        });
+    });
 }
 
 template <int MT, int NT, int WM, int WN>

@@ -37,6 +37,72 @@ struct ConvKArgs {
 };
 
 
+#include <type_traits>
+template <int I, int N, class F>
+__device__ __forceinline__ void dcvic_static_for(F&& f) {
+    if constexpr (I < N) { f(std::integral_constant<int, I>{}); dcvic_static_for<I + 1, N>(f); }
+}
+
+// Epilogue of one accumulator group: NV values of one lane that share the output pixel `pix` and differ in the output
+// channel co = co_of(r).  bias -> activation -> (+ residual) -> (beta-FT affine) -> store, in that order (the reference's
+// layer order).  The optional inputs are fetched in BATCHES of NV independent loads under one uniform branch each: with
+// the test inside the element loop hipcc branches around every load and waits vmcnt(0) per element -- measured on the
+// 3x3 DMA kernel as 148 k cycles (10 % of a workgroup's life) of serialised ~2 us round trips.  Channels past Cout are
+// clamped for the loads and masked for the store.
+template <int NV, int B, bool RES, bool AFF, class AccT, class CoF>
+__device__ __forceinline__ void dcvic_conv_epilogue(const ConvKArgs& K, int n, const AccT& accv, CoF co_of, long long pix, long long HWo) {
+    // B = loads in flight per optional input: 8 where the register budget allows, 4 for the 128-accumulator tiles.
+    // RES / AFF are resolved by the caller OUTSIDE its tile loops (dcvic_epilogue_dispatch), so that all optional inputs
+    // of a batch are requested before the first one is used.
+    static_assert(NV % B == 0, "group size");
+    const int cmax = K.Cout - 1;
+    float* const op = K.out + (long long)n * K.out_bs + pix;
+    const float* const rp = RES ? K.res + (long long)n * K.res_bs + pix : nullptr;
+    const long long ab = (long long)n * K.aff_bs;
+#pragma unroll
+    for (int r0 = 0; r0 < NV; r0 += B) {
+        float v[B], bv[B], rv[B], sv[B], tv[B];
+        if (K.bias) {
+#pragma unroll
+            for (int r = 0; r < B; ++r) bv[r] = K.bias[min(co_of(r0 + r), cmax)];
+        } else {
+#pragma unroll
+            for (int r = 0; r < B; ++r) bv[r] = 0.f;
+        }
+        if constexpr (RES) {
+#pragma unroll
+            for (int r = 0; r < B; ++r) rv[r] = rp[(long long)min(co_of(r0 + r), cmax) * HWo];
+        }
+        if constexpr (AFF) {
+#pragma unroll
+            for (int r = 0; r < B; ++r) { const int c = min(co_of(r0 + r), cmax); sv[r] = K.affs[ab + c]; tv[r] = K.afft[ab + c]; }
+        }
+#pragma unroll
+        for (int r = 0; r < B; ++r) {
+            v[r] = accv[r0 + r];
+            if (K.bias) v[r] += bv[r];                         // "+ 0" would turn -0 into +0: keep the no-bias path exact
+            v[r] = dcvic_act(v[r], K.act);
+            if constexpr (RES) v[r] += rv[r];
+            if constexpr (AFF) v[r] = v[r] * (1.f + sv[r]) + tv[r];
+        }
+#pragma unroll
+        for (int r = 0; r < B; ++r) {
+            const int co = co_of(r0 + r);
+            if (co <= cmax) op[(long long)co * HWo] = v[r];
+        }
+    }
+}
+
+// calls f(std::bool_constant<RES>, std::bool_constant<AFF>) for the launch's (residual?, affine?) combination
+template <class F>
+__device__ __forceinline__ void dcvic_epilogue_dispatch(const ConvKArgs& K, F&& f) {
+    if (K.res) {
+        if (K.affs) f(std::true_type{}, std::true_type{}); else f(std::true_type{}, std::false_type{});
+    } else {
+        if (K.affs) f(std::false_type{}, std::true_type{}); else f(std::false_type{}, std::false_type{});
+    }
+}
+
 // defined in conv3x3.hip: returns DCVIC_OK after launching, or 1 if the layer is not eligible
 int dcvic_try_conv3x3_dma(const ConvKArgs& K, int n_src, bool upsample, int cls, hipStream_t st, int* variant_out);
 
