@@ -475,3 +475,36 @@ def test_conv_upsample_phases_dma_bit_identical(dev):
     assert torch.equal(gen, dma)
     ref = torch.nn.functional.conv2d(torch.nn.functional.interpolate(x.cpu(), scale_factor=2.0, mode="nearest"), w.cpu(), b.cpu(), padding=1)
     close(dma, ref, rtol=1e-4, atol=1e-4)
+
+
+def test_conv3x3_dma_epilogues_bit_identical(dev):
+    """The DMA tap kernel's epilogue against the generic kernel's: bias / activation / residual / affine combinations
+    (each its own compile-time path), partial tiles (W = 36, W = 34) and a channel-offset output view."""
+    from dc_vic_amd import ops
+    from dc_vic_amd._lib import lib
+    L = lib()
+    try:
+        for ci, (H, W, N) in enumerate(((64, 64, 24), (40, 36, 40), (40, 34, 40))):
+            C = 128
+            x = rnd(N, C, H, W, seed=1400 + ci).to(dev)
+            w = rnd(C, C, 3, 3, seed=1410 + ci, scale=0.03).to(dev)
+            b = rnd(C, seed=1420 + ci, scale=0.1).to(dev)
+            res = rnd(N, C, H, W, seed=1430 + ci).to(dev)
+            aff = (rnd(N, C, seed=1440 + ci, scale=0.2).to(dev), rnd(N, C, seed=1450 + ci, scale=0.2).to(dev))
+            plan = ops.ConvPlan(w, b, "conv", pad=(1, 1))
+            big = torch.empty((N, C + 1, H, W), device=dev)                    # channel-offset view: misaligned unless H*W % 4 == 0
+            outs = {}
+            for mode, use_dma in (("generic", 0), ("dma", 1)):
+                L.dcvic_conv_set_tuning(use_dma, 0, -1)
+                y0 = plan(x)
+                v0 = int(L.dcvic_conv_last_variant())
+                y1 = plan(x, act=ops.ACT_SWISH, res=res)
+                y2 = plan(x, act=ops.ACT_RELU, res=res, affine=aff)
+                y3 = plan(x, affine=aff, use_bias=False)
+                y4 = plan(x, out=big[:, 1:], res=res).clone()
+                outs[mode] = (y0, y1, y2, y3, y4, v0)
+            assert outs["dma"][5] == 9000 and outs["generic"][5] < 7000, (ci, outs["dma"][5], outs["generic"][5])
+            for k in range(5):
+                assert torch.equal(outs["dma"][k], outs["generic"][k]), f"case {ci} output {k}"
+    finally:
+        L.dcvic_conv_set_tuning(1, 1, 2)
