@@ -249,8 +249,10 @@ __global__ void conv_pack_kernel(const float* __restrict__ w, float* __restrict_
 // ------------------------------------------------------------------------------------------------
 // tile variants: desc.cfg = TC class (fixes the weight pack), the pixel-tile size P is chosen per launch
 static const int kClassTC[4] = {128, 64, 32, 96};
-static const int kClassNP[4] = {3, 3, 2, 2};
-static const int kClassP[4][3] = {{256, 128, 64}, {256, 128, 64}, {256, 128, 0}, {256, 128, 0}};
+static const int kClassNP[4] = {3, 3, 4, 2};
+// class 2 also has 64- and 32-pixel tiles (conv_async16.hip only): below the 32x32-per-wave grain, for launches that
+// would otherwise leave most CUs idle (N = 1 .. 4 decoding, 16x16 maps)
+static const int kClassP[4][4] = {{256, 128, 64, 0}, {256, 128, 64, 0}, {256, 128, 64, 32}, {256, 128, 0, 0}};
 static inline int cfg_TC(int c) { return kClassTC[c]; }
 
 static int g_num_cu = 0;
@@ -270,6 +272,7 @@ static int tile_width_log(int Wout) {
 // tiles x how well the grid fills the CUs x a tile-efficiency prior (bigger tiles amortise staging better).
 static double variant_score(int cls, int P, int Cout, int N, int Hout, int Wout, int upsample, int num_cu) {
     if (P <= 0) return -1.0;
+    if (cls == 2 && P < 128 && (upsample || !g_use_async || !g_use_async16)) return -1.0;
     const int TC = kClassTC[cls];
     const int TW = 1 << tile_width_log(Wout);
     const int TH = P / TW;
@@ -278,7 +281,7 @@ static double variant_score(int cls, int P, int Cout, int N, int Hout, int Wout,
     const double wg = (double)N * ((Hout + TH - 1) / TH) * ((Wout + TW - 1) / TW) * cot;
     const double useful = (double)Cout / (cot * TC) * ((double)Hout * Wout) / ((double)((Hout + TH - 1) / TH) * TH * ((Wout + TW - 1) / TW) * TW);
     const double fill = wg >= 1.5 * num_cu ? 1.0 : wg / (1.5 * num_cu);
-    const double effP = P == 256 ? 1.0 : (P == 128 ? 0.93 : 0.85);
+    const double effP = P == 256 ? 1.0 : (P == 128 ? 0.93 : (P == 64 ? 0.85 : 0.75));
     const double effC = TC == 128 ? 1.0 : (TC == 96 ? 0.97 : (TC == 64 ? 0.93 : 0.80));
     return useful * fill * effP * effC;
 }
@@ -539,6 +542,12 @@ extern "C" int dcvic_conv2d_f32(const dcvic_conv_desc* d, const float* packed, c
         int var = 9000;
         const int rc = dcvic_try_conv3x3_dma(K, io->n_src, ups, cls, st, &var);
         if (rc <= 0) { g_last_variant = var; return rc; }
+    }
+    if (cls == 2 && P < 128) {
+        const int rc = dcvic_try_conv_async16(K, cls, P, st);
+        if (rc <= 0) { g_last_variant = 8500 + cls * 100 + P / 32; return rc; }
+        dcvic_set_error("conv2d: %d-pixel tile not launchable for this layer", P);
+        return DCVIC_EINVAL;
     }
     if (g_use_dma && d->T == 1) {
         // 1x1: flat 256-pixel tiles, DMA-pipelined GEMM (needs about a workgroup per CU to pay off)

@@ -30,10 +30,11 @@ __device__ __forceinline__ void static16_for(F&& f) {
     if constexpr (I < N) { f(std::integral_constant<int, I>{}); static16_for<I + 1, N>(f); }
 }
 
-template <int MT, int NT, int WM, int WN, bool H2>
+// M16 x N16: the wave's tile in units of 16 output channels x 16 pixels; WM x WN waves per workgroup
+template <int M16, int N16, int WM, int WN, bool H2>
 __global__ __launch_bounds__(NTHREADS, 2) void conv_mfma_async16_kernel(const ConvKArgs K, const int xs_floats, const int ws_floats) {
-    constexpr int TC = WM * MT * 32;
-    constexpr int P = WN * NT * 32;
+    constexpr int TC = WM * M16 * 16;
+    constexpr int P = WN * N16 * 16;
     constexpr int VPT = KC * TC / 4;                 // float4 per weight slab
     extern __shared__ __attribute__((aligned(16))) float smem[];
     // [2][xs_floats] patches, then [2][ws_floats] weight slabs
@@ -63,12 +64,11 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_mfma_async16_kernel(const Co
 
     // 16x16x4 operand layout: lane l supplies row/col (l & 15) of k = (l >> 4); a 16x16 accumulator holds rows
     // 4*(l >> 4) + r (r < 4) of column (l & 15)
-    constexpr int M16 = 2 * MT, N16 = 2 * NT;
     const int l16 = lane & 15, lq = lane >> 4;
     int pty[N16], ptx[N16], bbase[N16];
 #pragma unroll
     for (int nt = 0; nt < N16; ++nt) {
-        const int p = wn * (NT * 32) + nt * 16 + l16;
+        const int p = wn * (N16 * 16) + nt * 16 + l16;
         pty[nt] = p >> K.TWlog;
         ptx[nt] = p & (TW - 1);
         bbase[nt] = (pty[nt] * K.stride) * K.PW + ptx[nt] * K.stride + lq * K.plane;
@@ -93,7 +93,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_mfma_async16_kernel(const Co
             for (int mt = 0; mt < M16; ++mt)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const int co = cotile * TC + wm * (MT * 32) + mt * 16 + 4 * lq + r;
+                    const int co = cotile * TC + wm * (M16 * 16) + mt * 16 + 4 * lq + r;
                     if (co < K.Cout) acc[mt][nt][r] = K.init[(long long)n * K.init_bs + (long long)co * HWi + pix];
                 }
         }
@@ -190,7 +190,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_mfma_async16_kernel(const Co
         const int tiy0 = tg / K.TX, tix0 = tg - tiy0 * K.TX;
         const int toff0 = (K.dy0 + tiy0 * K.dstep - K.dy_min) * K.PW + (K.dx0 + tix0 * K.dstep - K.dx_min);
         const int row_step = K.dstep * K.PW - K.TX * K.dstep;   // extra step from the last tap of a row to the next row
-        const unsigned avec = 4u * (unsigned)(lq * TC + wm * (MT * 32) + l16);
+        const unsigned avec = 4u * (unsigned)(lq * TC + wm * (M16 * 16) + l16);
         unsigned bvec[N16];
 #pragma unroll
         for (int nt = 0; nt < N16; ++nt) bvec[nt] = 4u * (unsigned)bbase[nt];
@@ -305,18 +305,18 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_mfma_async16_kernel(const Co
                 for (int mt = 0; mt < M16; ++mt)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) av[mt * 4 + r] = acc[mt][nt][r];
-                const int cob = cotile * TC + wm * (MT * 32) + 4 * lq;
+                const int cob = cotile * TC + wm * (M16 * 16) + 4 * lq;
                 dcvic_conv_epilogue<4 * M16, (4 * M16 < 8 ? 4 * M16 : 8), RES, AFF>(K, n, av, [cob](int q) { return cob + (q >> 2) * 16 + (q & 3); }, pix, HWo);
             }
         });
     });
 }
 
-template <int MT, int NT, int WM, int WN>
+template <int M16, int N16, int WM, int WN>
 static int launch_async16(const ConvKArgs& K, int xs_floats, int ws_floats, hipStream_t st) {
     static bool attr_set = false;
-    auto k1 = conv_mfma_async16_kernel<MT, NT, WM, WN, false>;
-    auto k2 = conv_mfma_async16_kernel<MT, NT, WM, WN, true>;
+    auto k1 = conv_mfma_async16_kernel<M16, N16, WM, WN, false>;
+    auto k2 = conv_mfma_async16_kernel<M16, N16, WM, WN, true>;
     if (!attr_set) {
         hipFuncSetAttribute(reinterpret_cast<const void*>(k1), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         hipFuncSetAttribute(reinterpret_cast<const void*>(k2), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -359,11 +359,14 @@ int dcvic_try_conv_async16(const ConvKArgs& Kin, int cls, int P, hipStream_t st)
     const int ws_floats = (slabs + 2) * KC * TC;
     if ((size_t)2 * (xs_floats + ws_floats) * sizeof(float) > 156 * 1024) return 1;
     switch (cls * 1000 + P) {
-        case 0 * 1000 + 64: return launch_async16<2, 1, 2, 2>(K, xs_floats, ws_floats, st);
-        case 1 * 1000 + 128: return launch_async16<1, 2, 2, 2>(K, xs_floats, ws_floats, st);
-        case 1 * 1000 + 64: return launch_async16<1, 1, 2, 2>(K, xs_floats, ws_floats, st);
-        case 2 * 1000 + 256: return launch_async16<1, 2, 1, 4>(K, xs_floats, ws_floats, st);
-        case 2 * 1000 + 128: return launch_async16<1, 1, 1, 4>(K, xs_floats, ws_floats, st);
+        case 0 * 1000 + 64: return launch_async16<4, 2, 2, 2>(K, xs_floats, ws_floats, st);    // 128 ch x 64 px
+        case 1 * 1000 + 128: return launch_async16<2, 4, 2, 2>(K, xs_floats, ws_floats, st);   //  64 ch x 128 px
+        case 1 * 1000 + 64: return launch_async16<2, 2, 2, 2>(K, xs_floats, ws_floats, st);    //  64 ch x 64 px
+        case 2 * 1000 + 256: return launch_async16<2, 4, 1, 4>(K, xs_floats, ws_floats, st);   //  32 ch x 256 px
+        case 2 * 1000 + 128: return launch_async16<2, 2, 1, 4>(K, xs_floats, ws_floats, st);   //  32 ch x 128 px
+        // tiles below the 32x32-per-wave grain, for launches that would leave CUs idle (N = 1 .. 4, 16x16 maps)
+        case 2 * 1000 + 64: return launch_async16<2, 1, 1, 4>(K, xs_floats, ws_floats, st);    //  32 ch x 64 px
+        case 2 * 1000 + 32: return launch_async16<1, 1, 2, 2>(K, xs_floats, ws_floats, st);    //  32 ch x 32 px
         default: return 1;
     }
 }

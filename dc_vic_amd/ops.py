@@ -59,9 +59,11 @@ def conv_kernel_name(variant: int) -> str:
         return "void conv3x3_dma_kernel<2, 2, 8>(ConvKArgs)"
     if 7000 <= variant < 8000:                       # conv1x1.hip: 7000 + cls
         return f"void conv1x1_dma_kernel<{(128, 64, 32, 96)[variant - 7000]}>(ConvKArgs)"
-    if 8500 <= variant < 9000:                       # conv_async16.hip: 8500 + cls*100 + P/32
+    if 8500 <= variant < 9000:                       # conv_async16.hip: 8500 + cls*100 + P/32 (tiles in units of 16)
         cls, p32 = divmod(variant - 8500, 100)
-        return f"void conv_mfma_async16_kernel<{_VARIANT_TILES.get((cls, p32 * 32), '?')}>(ConvKArgs, int, int)"
+        t16 = {(0, 64): "4, 2, 2, 2", (1, 128): "2, 4, 2, 2", (1, 64): "2, 2, 2, 2", (2, 256): "2, 4, 1, 4", (2, 128): "2, 2, 1, 4",
+               (2, 64): "2, 1, 1, 4", (2, 32): "1, 1, 2, 2"}.get((cls, p32 * 32), "?")
+        return f"void conv_mfma_async16_kernel<{t16}>(ConvKArgs, int, int)"
     if 8000 <= variant < 9000:                       # conv_async.hip: 8000 + cls*100 + P/32
         cls, p32 = divmod(variant - 8000, 100)
         return f"void conv_mfma_async_kernel<{_VARIANT_TILES.get((cls, p32 * 32), '?')}>(ConvKArgs, int, int)"
