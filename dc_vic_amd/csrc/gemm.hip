@@ -1,17 +1,20 @@
 // gemm.hip -- batched strided GEMM on the fp32 MFMA (attention score / value products of the ldm
 // AttnBlock, model.py:186-196).  C[b][m][n] = alpha * sum_k A[b][m][k] * B[b][k][n], k ascending
 // (one fmaf per term), so results do not depend on the grid or the batch size.
-// 128x128 output tile per workgroup, 4 waves as 2x2, each wave 2x2 MFMA 32x32x2 tiles; operands are
-// staged through LDS as [k][m] / [k][n] images (+1 word of row padding) from arbitrary element strides.
+// 128x128 (or, when that would leave CUs idle, 64x64) output tile per workgroup, 4 waves as 2x2, each wave
+// 2x2 (1x1) MFMA 32x32x2 tiles; operands are staged through LDS as [k][m] / [k][n] images (+1 word of row padding)
+// from arbitrary element strides.  The tile size never changes a value (one k-ordered chain per output).
 #include "common.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 #define GK 16
-#define GT 128
-#define GTP (GT + 1)
 
+template <int GT>
 __global__ __launch_bounds__(256, 2) void bgemm_kernel(const dcvic_gemm_args g) {
+    constexpr int GTP = GT + 1;
+    constexpr int WT = GT / 2;            // per-wave tile edge
+    constexpr int MI = WT / 32;           // 32x32 accumulators per wave and dimension
     __shared__ float As[GK * GTP];
     __shared__ float Bs[GK * GTP];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -25,11 +28,11 @@ __global__ __launch_bounds__(256, 2) void bgemm_kernel(const dcvic_gemm_args g) 
     const float* A = g.A + (long long)b * g.a_bs;
     const float* B = g.B + (long long)b * g.b_bs;
 
-    f32x16 acc[2][2];
+    f32x16 acc[MI][MI];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < MI; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < MI; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
@@ -53,28 +56,28 @@ __global__ __launch_bounds__(256, 2) void bgemm_kernel(const dcvic_gemm_args g) 
         __syncthreads();
 #pragma unroll
         for (int ks = 0; ks < GK / 2; ++ks) {
-            float a[2], bb[2];
+            float a[MI], bb[MI];
 #pragma unroll
-            for (int i = 0; i < 2; ++i) a[i] = As[(2 * ks + lane_k) * GTP + wm * 64 + i * 32 + lane_j];
+            for (int i = 0; i < MI; ++i) a[i] = As[(2 * ks + lane_k) * GTP + wm * WT + i * 32 + lane_j];
 #pragma unroll
-            for (int j = 0; j < 2; ++j) bb[j] = Bs[(2 * ks + lane_k) * GTP + wn * 64 + j * 32 + lane_j];
+            for (int j = 0; j < MI; ++j) bb[j] = Bs[(2 * ks + lane_k) * GTP + wn * WT + j * 32 + lane_j];
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+            for (int i = 0; i < MI; ++i)
 #pragma unroll
-                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], bb[j], acc[i][j], 0, 0, 0);
+                for (int j = 0; j < MI; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], bb[j], acc[i][j], 0, 0, 0);
         }
         __syncthreads();
     }
     float* C = g.C + (long long)b * g.c_bs;
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < MI; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int nn = n0 + wn * 64 + j * 32 + lane_j;
+        for (int j = 0; j < MI; ++j) {
+            const int nn = n0 + wn * WT + j * 32 + lane_j;
             if (nn >= g.N) continue;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int mm = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lane_k;
+                const int mm = m0 + wm * WT + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lane_k;
                 if (mm < g.M) C[(long long)mm * g.c_ms + nn] = g.alpha * acc[i][j][r];
             }
         }
@@ -84,9 +87,19 @@ extern "C" int dcvic_bgemm_f32(const dcvic_gemm_args* a, void* stream) {
     DCVIC_CHECK_ARG(a && a->A && a->B && a->C, "bgemm: null pointer");
     DCVIC_CHECK_ARG(a->batch > 0 && a->M > 0 && a->N > 0 && a->K > 0, "bgemm: bad sizes");
     DCVIC_CHECK_ARG(a->batch <= 65535, "bgemm: batch too large");
-    const int tiles = dcvic_cdiv(a->M, GT) * dcvic_cdiv(a->N, GT);
-    dim3 grid(tiles, a->batch);
-    bgemm_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(*a);
+    static int num_cu = 0;
+    if (num_cu == 0) {
+        int dev = 0, cu = 0;
+        num_cu = (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cu > 0) ? cu : 256;
+    }
+    const long long tiles128 = (long long)dcvic_cdiv(a->M, 128) * dcvic_cdiv(a->N, 128);
+    if (tiles128 * a->batch >= num_cu) {
+        dim3 grid((unsigned)tiles128, a->batch);
+        bgemm_kernel<128><<<grid, 256, 0, (hipStream_t)stream>>>(*a);
+    } else {                                              // small batch: 4x the workgroups
+        dim3 grid((unsigned)(dcvic_cdiv(a->M, 64) * dcvic_cdiv(a->N, 64)), a->batch);
+        bgemm_kernel<64><<<grid, 256, 0, (hipStream_t)stream>>>(*a);
+    }
     DCVIC_CHECK_LAUNCH("bgemm");
     return DCVIC_OK;
 }

@@ -508,3 +508,17 @@ def test_conv3x3_dma_epilogues_bit_identical(dev):
                 assert torch.equal(outs["dma"][k], outs["generic"][k]), f"case {ci} output {k}"
     finally:
         L.dcvic_conv_set_tuning(1, 1, 2)
+
+
+def test_bgemm_tile_sizes_bit_identical(dev):
+    """The batched GEMM picks 64x64 tiles when 128x128 ones would leave CUs idle (small batch); an item computed alone
+    (64-tiles) equals the same item inside a large batch (128-tiles) bit for bit, ragged sizes included."""
+    from dc_vic_amd import ops
+    Nb, M, Nn, K = 72, 200, 330, 96
+    A = rnd(Nb, M, K, seed=1500).to(dev); B = rnd(Nb, K, Nn, seed=1501).to(dev)
+    big = torch.empty(Nb, M, Nn, device=dev)
+    ops.bgemm(A, (M * K, K, 1), B, (K * Nn, Nn, 1), big, (M * Nn, Nn), Nb, M, Nn, K, alpha=0.37)
+    one = torch.empty(1, M, Nn, device=dev)
+    ops.bgemm(A[5:6].contiguous(), (M * K, K, 1), B[5:6].contiguous(), (K * Nn, Nn, 1), one, (M * Nn, Nn), 1, M, Nn, K, alpha=0.37)
+    assert torch.equal(one[0], big[5])
+    close(big, 0.37 * torch.bmm(A.cpu(), B.cpu()), rtol=1e-4, atol=1e-4)
