@@ -30,7 +30,7 @@ __global__ __launch_bounds__(Q_THREADS, 4) void conv1x1_dma_kernel(const ConvKAr
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int wave = tid >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // SGPR: LDS-DMA destinations stay scalar
     const int wm = wave / WN, wn = wave % WN;
     const int lane_k = lane >> 5, lane_j = lane & 31;
 
@@ -60,34 +60,47 @@ __global__ __launch_bounds__(Q_THREADS, 4) void conv1x1_dma_kernel(const ConvKAr
     const int pl = p0 + lane * 4;
     const bool pin = pl < HW;
 
+    // Running pointers (same idea as conv3x3.hip): this wave's two pixel rows of a stage and this thread's weight pieces
+    // advance by fixed strides; only a change of source in the virtual concat re-derives them.
+    const float* xrow[Q_CH / 8];
+    int xleft[Q_CH / 8];                                          // channels left in the current source, per row slot
+    long long xstep[Q_CH / 8];                                    // elements per stage (0 while the slot reads the zero row)
+    auto x_rebase = [&](int j, int c) {                          // row slot j -> absolute channel c
+        xstep[j] = (long long)Q_CH * HW;
+        if (c >= K.Cin || !pin) { xrow[j] = dcvic_zero_row; xleft[j] = 1 << 30; xstep[j] = 0; return; }
+        int si = 0, cl = c;
+        if (cl >= K.srcC[0]) { cl -= K.srcC[0]; si = 1; if (cl >= K.srcC[1]) { cl -= K.srcC[1]; si = 2; } }
+        xrow[j] = K.src[si] + (long long)n * K.src_bs[si] + (long long)cl * HW + pl;
+        xleft[j] = min(K.srcC[si] - cl, K.Cin - c);
+    };
+#pragma unroll
+    for (int j = 0; j < Q_CH / 8; ++j) x_rebase(j, wave + 8 * j);
+    constexpr int NV = WS / 4;                                    // float4 of weights per stage
+    constexpr int NWJ = (NV + Q_THREADS - 1) / Q_THREADS;
+    const float* wrow[NWJ];                                       // (float4 rows kept as float*: see conv3x3.hip)
+#pragma unroll
+    for (int j = 0; j < NWJ; ++j) wrow[j] = wbase + 4 * (j * Q_THREADS + tid);
+
     auto issue = [&](int stage, int buf) {
         float* xb = smem + buf * BUF;
         float* wb = xb + XS;
-        // pixel rows: wave w moves channels w and w + 8 of the stage
 #pragma unroll
         for (int j = 0; j < Q_CH / 8; ++j) {
-            const int kk = wave + 8 * j;
-            int c = stage * Q_CH + kk;
-            const float* gp = dcvic_zero_row;
-            if (pin && c < K.Cin) {
-                int si = 0;
-                if (c >= K.srcC[0]) { c -= K.srcC[0]; si = 1; if (c >= K.srcC[1]) { c -= K.srcC[1]; si = 2; } }
-                gp = K.src[si] + (long long)n * K.src_bs[si] + (long long)c * HW + pl;
-            }
-            __builtin_amdgcn_global_load_lds(gp, (lds_ptr_t)(xb + kk * Q_P), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds(xrow[j], (lds_ptr_t)(xb + (wave + 8 * j) * Q_P), 16, 0, 0);
+            xleft[j] -= Q_CH;
+            if (xleft[j] > 0) xrow[j] += xstep[j];
+            else x_rebase(j, (stage + 1) * Q_CH + wave + 8 * j);
         }
-        // weight rows: Q_CH x TCv floats, contiguous in the pack (two chunks); chunks past the end are zero-filled by the pack
-        const int chunk0 = stage * (Q_CH / KC);
-        const int nfl = min(Q_CH / KC, K.n_chunks - chunk0) * (KC * TCv);           // floats available
-        const float4* w4 = reinterpret_cast<const float4*>(wbase + (long long)chunk0 * (KC * TCv));
-        constexpr int NV = WS / 4;                                                  // float4 per stage
+        // weight rows: Q_CH x TCv floats, contiguous in the pack (two chunks); a missing last chunk reads zeros
+        const int nfl = min(Q_CH / KC, K.n_chunks - stage * (Q_CH / KC)) * (KC * TCv);        // floats available
 #pragma unroll
-        for (int j = 0; j < (NV + Q_THREADS - 1) / Q_THREADS; ++j) {
+        for (int j = 0; j < NWJ; ++j) {
             const int v0 = j * Q_THREADS + wave * 64;                                // wave-uniform
             if (v0 < NV) {
-                const float4* gp4 = (v0 * 4 < nfl) ? (w4 + v0 + lane) : reinterpret_cast<const float4*>(dcvic_zero_row);
-                __builtin_amdgcn_global_load_lds(gp4, (lds_ptr_t)(wb + v0 * 4), 16, 0, 0);
+                const float* gp = (v0 * 4 < nfl) ? wrow[j] : dcvic_zero_row;
+                __builtin_amdgcn_global_load_lds(reinterpret_cast<const float4*>(gp), (lds_ptr_t)(wb + v0 * 4), 16, 0, 0);
             }
+            wrow[j] += WS;
         }
     };
 
