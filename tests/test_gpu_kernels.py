@@ -522,3 +522,46 @@ def test_bgemm_tile_sizes_bit_identical(dev):
     ops.bgemm(A[5:6].contiguous(), (M * K, K, 1), B[5:6].contiguous(), (K * Nn, Nn, 1), one, (M * Nn, Nn), 1, M, Nn, K, alpha=0.37)
     assert torch.equal(one[0], big[5])
     close(big, 0.37 * torch.bmm(A.cpu(), B.cpu()), rtol=1e-4, atol=1e-4)
+
+
+def test_conv_dispatch_fuzz_bit_identical(dev):
+    """Random layer geometries through the full dispatcher (DMA tap / 1x1 kernels, async twins, small tiles) against the
+    generic kernel alone: bit-identical; and against torch's conv2d within fp32 re-association tolerance."""
+    from dc_vic_amd import ops
+    from dc_vic_amd._lib import lib
+    L = lib()
+    rs = np.random.RandomState(20261004)
+    seen = set()
+    try:
+        for it in range(48):
+            k = int(rs.choice([1, 1, 3, 3, 3, 5]))
+            stride = int(rs.choice([1, 1, 1, 2])) if k > 1 else 1
+            cin = int(rs.choice([3, 8, 24, 96, 100, 128, 192, 256, 320]))
+            cout = int(rs.choice([3, 32, 64, 96, 128, 192, 256]))
+            H = int(rs.choice([4, 8, 13, 16, 32, 40, 64])); W = int(rs.choice([4, 8, 12, 16, 32, 36, 64]))
+            N = int(rs.choice([1, 2, 5, 16, 33]))
+            if N * cin * H * W > 24e6 or N * cout * H * W > 24e6:
+                N = max(1, int(24e6 // (max(cin, cout) * H * W)))
+            nsplit = int(rs.choice([1, 1, 2, 3])) if cin >= 24 and cin % 8 == 0 else 1
+            cuts = sorted(rs.choice(np.arange(8, cin, 8), size=nsplit - 1, replace=False).tolist()) if nsplit > 1 else []
+            parts = [b - a for a, b in zip([0] + cuts, cuts + [cin])]
+            srcs = [rnd(N, c, H, W, seed=5000 + 7 * it + j).to(dev) for j, c in enumerate(parts)]
+            w = rnd(cout, cin, k, k, seed=6000 + it, scale=(cin * k * k) ** -0.5).to(dev)
+            b = rnd(cout, seed=7000 + it, scale=0.1).to(dev)
+            plan = ops.ConvPlan(w, b, "conv", stride=stride, pad=(k // 2, k // 2))
+            with_res = bool(rs.randint(2))
+            outs = {}
+            for mode, (dma, asy) in (("generic", (0, 0)), ("full", (1, 1))):
+                L.dcvic_conv_set_tuning(dma, asy, 2)
+                y = plan(srcs)
+                res = rnd(*y.shape, seed=8000 + it).to(dev) if with_res else None
+                y2 = plan(srcs, act=ops.ACT_LRELU02, res=res)
+                outs[mode] = (y, y2, int(L.dcvic_conv_last_variant()))
+            seen.add(outs["full"][2] // 100)
+            assert torch.equal(outs["full"][0], outs["generic"][0]) and torch.equal(outs["full"][1], outs["generic"][1]), \
+                (it, k, stride, parts, cout, H, W, N, outs["full"][2], outs["generic"][2])
+            ref = F.conv2d(torch.cat(srcs, 1).cpu(), w.cpu(), b.cpu(), stride=stride, padding=k // 2)
+            close(outs["full"][0], ref, rtol=2e-4, atol=2e-4)
+    finally:
+        L.dcvic_conv_set_tuning(1, 1, 2)
+    assert len(seen) >= 4, f"the fuzz run should reach several kernel families, got variant groups {sorted(seen)}"
