@@ -24,13 +24,17 @@ typedef __attribute__((address_space(3))) void* lds_ptr_t;
 
 __device__ float dcvic_zero_word[16];   // zero-initialised: source of padded lanes
 
-#define D_TC 128
 #define D_TW 32
 #define D_TH 8
 #define D_THREADS 512
 
-template <int TY, int TX, int SKC>
+// TCV = 128: waves 2 (channel halves) x 4 (row pairs), each 64 ch x 2 rows (MT = NT = 2);
+// TCV =  96: waves 1 x 8 (rows), each 96 ch x 1 row (MT = 3, NT = 1) -- the ELIC 96 / 192-channel layers
+template <int TY, int TX, int SKC, int TCV>
 __global__ __launch_bounds__(D_THREADS, 4) void conv3x3_dma_kernel(const ConvKArgs K) {
+    constexpr int D_TC = TCV;
+    constexpr int WM = (TCV == 128) ? 2 : 1, WN = 8 / WM;
+    constexpr int MT = TCV / (32 * WM), NT = D_TH / WN;
     constexpr int T = TY * TX;
     constexpr int D_PW = D_TW + TX - 1;
     constexpr int D_PLANE = (D_TH + TY - 1) * D_PW;
@@ -45,7 +49,7 @@ __global__ __launch_bounds__(D_THREADS, 4) void conv3x3_dma_kernel(const ConvKAr
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // 0..7, an SGPR: LDS-DMA destinations stay scalar
-    const int wm = wave >> 2, wn = wave & 3;
+    const int wm = wave / WN, wn = wave % WN;
     const int lane_k = lane >> 5, lane_j = lane & 31;
 
     int b;
@@ -93,11 +97,11 @@ __global__ __launch_bounds__(D_THREADS, 4) void conv3x3_dma_kernel(const ConvKAr
     };
     x_rebase(0);
 
-    f32x16 acc[2][2];
+    f32x16 acc[MT][NT];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < MT; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < NT; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
@@ -106,7 +110,7 @@ __global__ __launch_bounds__(D_THREADS, 4) void conv3x3_dma_kernel(const ConvKAr
 
     // weight pieces: float4 index v = tid + j * 512 of the stage's [tap][SKC][128] rows -> (tap t, element i) is fixed per
     // thread; the stage base walks the pack: + SKC rows inside a chunk, then to the next chunk
-    constexpr int NWJ = (TY * TX * SKC * (D_TC / 4) + D_THREADS - 1) / D_THREADS;
+    constexpr int NWJ = (TY * TX * SKC * (TCV / 4) + D_THREADS - 1) / D_THREADS;
     const float* wp4[NWJ];                                       // float4 rows, kept as float*: with a dependent-size float4* array captured by the lambdas hipcc 7.2 silently drops the kernel's host stub
 #pragma unroll
     for (int j = 0; j < NWJ; ++j) {
@@ -124,7 +128,7 @@ __global__ __launch_bounds__(D_THREADS, 4) void conv3x3_dma_kernel(const ConvKAr
             __builtin_amdgcn_global_load_lds(xp[s], (lds_ptr_t)(xb + wave * 64 + s * D_THREADS), 4, 0, 0);
 #pragma unroll
         for (int j = 0; j < NWJ; ++j)
-            if (j * D_THREADS + wave * 64 < NV)                   // wave-uniform (NV is a multiple of 64)
+            if (j * D_THREADS + tid < NV)                         // whole waves for TCV = 128; the last wave is partial for 96
                 __builtin_amdgcn_global_load_lds(reinterpret_cast<const float4*>(wp4[j]), (lds_ptr_t)(wb + (wave * 64 + j * D_THREADS) * 4), 16, 0, 0);
         // advance to the next stage
         x_left -= D_SKC;
@@ -143,8 +147,8 @@ __global__ __launch_bounds__(D_THREADS, 4) void conv3x3_dma_kernel(const ConvKAr
     issue(0, 0);
     __syncthreads();
 
-    const int xlane = lane_k * D_PLANE + (wn * 2) * D_PW + lane_j;
-    const int alane = lane_k * D_TC + wm * 64 + lane_j;
+    const int xlane = lane_k * D_PLANE + (wn * NT) * D_PW + lane_j;
+    const int alane = lane_k * D_TC + wm * (MT * 32) + lane_j;
     for (int stage = 0; stage < n_stages; ++stage) {
         const int buf = stage & 1;
         if (stage + 1 < n_stages) issue(stage + 1, buf ^ 1);
@@ -152,30 +156,32 @@ __global__ __launch_bounds__(D_THREADS, 4) void conv3x3_dma_kernel(const ConvKAr
         const float* wb = smem + buf * D_BUF + D_XS + alane;
         // T x SKC/2 steps (taps x channel pairs), software pipelined: the fragments of step s+1 are in flight
         // while the four MFMAs of step s issue
-        float a_cur[2], b_cur[2], a_nxt[2], b_nxt[2];
+        float a_cur[MT], b_cur[NT], a_nxt[MT], b_nxt[NT];
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt) a_cur[mt] = wb[mt * 32];
+        for (int mt = 0; mt < MT; ++mt) a_cur[mt] = wb[mt * 32];
 #pragma unroll
-        for (int nt = 0; nt < 2; ++nt) b_cur[nt] = xb[nt * D_PW];
+        for (int nt = 0; nt < NT; ++nt) b_cur[nt] = xb[nt * D_PW];
 #pragma unroll
         for (int step = 0; step < T * D_SKC / 2; ++step) {
             if (step + 1 < T * D_SKC / 2) {
                 const int t = (step + 1) / (D_SKC / 2), ks = (step + 1) % (D_SKC / 2);
                 const int ky = t / TX, kx = t - TX * ky;
 #pragma unroll
-                for (int mt = 0; mt < 2; ++mt) a_nxt[mt] = wb[(t * D_SKC + 2 * ks) * D_TC + mt * 32];
+                for (int mt = 0; mt < MT; ++mt) a_nxt[mt] = wb[(t * D_SKC + 2 * ks) * D_TC + mt * 32];
 #pragma unroll
-                for (int nt = 0; nt < 2; ++nt) b_nxt[nt] = xb[(2 * ks) * D_PLANE + (nt + ky) * D_PW + kx];
+                for (int nt = 0; nt < NT; ++nt) b_nxt[nt] = xb[(2 * ks) * D_PLANE + (nt + ky) * D_PW + kx];
             }
             __builtin_amdgcn_sched_barrier(0);   // keep the prefetch of step s+1 ahead of the MFMAs of step s
 #pragma unroll
-            for (int mt = 0; mt < 2; ++mt)
+            for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-                for (int nt = 0; nt < 2; ++nt)
+                for (int nt = 0; nt < NT; ++nt)
                     acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[mt], b_cur[nt], acc[mt][nt], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int i = 0; i < 2; ++i) { a_cur[i] = a_nxt[i]; b_cur[i] = b_nxt[i]; }
+            for (int i = 0; i < MT; ++i) a_cur[i] = a_nxt[i];
+#pragma unroll
+            for (int i = 0; i < NT; ++i) b_cur[i] = b_nxt[i];
         }
         __syncthreads();
     }
@@ -184,14 +190,14 @@ __global__ __launch_bounds__(D_THREADS, 4) void conv3x3_dma_kernel(const ConvKAr
     const long long HWo = (long long)K.Hfull * K.Wfull;
     dcvic_epilogue_dispatch(K, [&](auto res_, auto aff_) {
         constexpr bool RES = decltype(res_)::value, AFF = decltype(aff_)::value;
-        dcvic_static_for<0, 2>([&](auto nt_) {
+        dcvic_static_for<0, NT>([&](auto nt_) {
             constexpr int nt = decltype(nt_)::value;
-            const int oy = oy0 + wn * 2 + nt, ox = ox0 + lane_j;
+            const int oy = oy0 + wn * NT + nt, ox = ox0 + lane_j;
             if (oy < K.Hout && ox < K.Wout) {
                 const long long pix = (long long)(oy * K.osy + K.ooy) * K.Wfull + (ox * K.osx + K.oox);
-                dcvic_static_for<0, 2>([&](auto mt_) {
+                dcvic_static_for<0, MT>([&](auto mt_) {
                     constexpr int mt = decltype(mt_)::value;
-                    const int cob = cotile * D_TC + (wm * 2 + mt) * 32 + 4 * lane_k;
+                    const int cob = cotile * D_TC + (wm * MT + mt) * 32 + 4 * lane_k;
                     dcvic_conv_epilogue<16, (AFF ? 4 : 8), RES, AFF>(K, n, acc[mt][nt], [cob](int r) { return cob + (r & 3) + 8 * (r >> 2); }, pix, HWo);
                 });
             }
@@ -199,13 +205,13 @@ __global__ __launch_bounds__(D_THREADS, 4) void conv3x3_dma_kernel(const ConvKAr
     });
 }
 
-template <int TY, int TX, int SKC>
+template <int TY, int TX, int SKC, int TCV>
 static int launch_tap_dma(const ConvKArgs& A, hipStream_t st) {
     static bool attr_set = false;
-    auto k = conv3x3_dma_kernel<TY, TX, SKC>;
+    auto k = conv3x3_dma_kernel<TY, TX, SKC, TCV>;
     constexpr int PLANE = (D_TH + TY - 1) * (D_TW + TX - 1);
     constexpr int XS = ((SKC * PLANE + D_THREADS - 1) / D_THREADS) * D_THREADS;
-    const size_t lds = (size_t)2 * (XS + TY * TX * SKC * D_TC) * sizeof(float);
+    const size_t lds = (size_t)2 * (XS + TY * TX * SKC * TCV) * sizeof(float);
     if (!attr_set) {
         hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
@@ -215,10 +221,10 @@ static int launch_tap_dma(const ConvKArgs& A, hipStream_t st) {
     return DCVIC_OK;
 }
 
-// returns DCVIC_OK (variant_out: 9000 = 3x3, 9001 = 2x2 phases) after launching, or 1 if the layer is not eligible
+// returns DCVIC_OK (variant_out: 9000 = 3x3, 9001 = 2x2 phases, 9003 = 3x3 with 96-channel tiles) after launching, or 1 if the layer is not eligible
 int dcvic_try_conv3x3_dma(const ConvKArgs& Kin, int n_src, bool upsample, int cls, hipStream_t st, int* variant_out) {
     const ConvKArgs& K = Kin;
-    if (upsample || cls != 0 || K.TWlog != 5 || K.init || K.stride != 1 || K.dstep != 1) return 1;
+    if (upsample || (cls != 0 && cls != 3) || K.TWlog != 5 || K.init || K.stride != 1 || K.dstep != 1) return 1;
     if ((long long)K.H * K.W * KC >= (1ll << 31)) return 1;
     const bool fam3 = K.halves == 2;                                  // 3x3/s1/p1 family, channels % 8 == 0
     bool ph2 = !fam3 && K.T == 4 && K.TX == 2;                        // 2x2 sub-pixel phase of upsample + conv3x3
@@ -227,12 +233,14 @@ int dcvic_try_conv3x3_dma(const ConvKArgs& Kin, int n_src, bool upsample, int cl
         for (int i = 0; i < n_src; ++i) if (K.srcC[i] % KC) ph2 = false;
     }
     if (!fam3 && !ph2) return 1;
+    if (cls == 3 && !fam3) return 1;                                  // 96-channel tiles: the 3x3 family only
     ConvKArgs A = K;
     A.tiles_y = (K.Hout + D_TH - 1) / D_TH;
     A.tiles_x = (K.Wout + D_TW - 1) / D_TW;
     const long long blocks = (long long)K.N * A.tiles_y * A.tiles_x * K.n_cotiles;
     if (blocks >= (1ll << 31)) return 1;
     A.nblocks = (int)blocks;
-    if (variant_out) *variant_out = fam3 ? 9000 : 9001;
-    return fam3 ? launch_tap_dma<3, 3, 4>(A, st) : launch_tap_dma<2, 2, 8>(A, st);
+    if (variant_out) *variant_out = cls == 3 ? 9003 : (fam3 ? 9000 : 9001);
+    if (cls == 3) return launch_tap_dma<3, 3, 4, 96>(A, st);
+    return fam3 ? launch_tap_dma<3, 3, 4, 128>(A, st) : launch_tap_dma<2, 2, 8, 128>(A, st);
 }

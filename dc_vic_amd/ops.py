@@ -54,9 +54,11 @@ _VARIANT_TILES = {(0, 256): "2, 4, 2, 2", (0, 128): "2, 2, 2, 2", (0, 64): "2, 1
 def conv_kernel_name(variant: int) -> str:
     """Kernel name as rocprofv3 prints it, from dcvic_conv_last_variant()."""
     if variant == 9000:
-        return "void conv3x3_dma_kernel<3, 3, 4>(ConvKArgs)"
+        return "void conv3x3_dma_kernel<3, 3, 4, 128>(ConvKArgs)"
     if variant == 9001:
-        return "void conv3x3_dma_kernel<2, 2, 8>(ConvKArgs)"
+        return "void conv3x3_dma_kernel<2, 2, 8, 128>(ConvKArgs)"
+    if variant == 9003:
+        return "void conv3x3_dma_kernel<3, 3, 4, 96>(ConvKArgs)"
     if 7000 <= variant < 8000:                       # conv1x1.hip: 7000 + cls
         return f"void conv1x1_dma_kernel<{(128, 64, 32, 96)[variant - 7000]}>(ConvKArgs)"
     if 8500 <= variant < 9000:                       # conv_async16.hip: 8500 + cls*100 + P/32 (tiles in units of 16)

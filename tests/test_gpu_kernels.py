@@ -565,3 +565,28 @@ def test_conv_dispatch_fuzz_bit_identical(dev):
     finally:
         L.dcvic_conv_set_tuning(1, 1, 2)
     assert len(seen) >= 4, f"the fuzz run should reach several kernel families, got variant groups {sorted(seen)}"
+
+
+def test_conv3x3_dma_96_channel_tiles_bit_identical(dev):
+    """The DMA tap kernel's 96-channel-tile build (ELIC 96 / 192-channel 3x3 layers) against the generic kernel."""
+    from dc_vic_amd import ops
+    from dc_vic_amd._lib import lib
+    L = lib()
+    try:
+        for ci, (cin, cout, H, W, N) in enumerate(((96, 96, 64, 64, 24), (192, 192, 48, 40, 16), (96, 192, 64, 64, 12))):
+            x = rnd(N, cin, H, W, seed=1600 + ci).to(dev)
+            w = rnd(cout, cin, 3, 3, seed=1610 + ci, scale=0.03).to(dev)
+            b = rnd(cout, seed=1620 + ci, scale=0.1).to(dev)
+            res = rnd(N, cout, H, W, seed=1630 + ci).to(dev)
+            plan = ops.ConvPlan(w, b, "conv", pad=(1, 1))
+            outs = {}
+            for mode, use_dma in (("generic", 0), ("dma", 1)):
+                L.dcvic_conv_set_tuning(use_dma, 0, -1)
+                y0 = plan(x, act=ops.ACT_RELU)
+                v0 = int(L.dcvic_conv_last_variant())
+                y1 = plan(x, res=res)
+                outs[mode] = (y0, y1, v0)
+            assert outs["dma"][2] == 9003 and outs["generic"][2] < 7000, (ci, outs["dma"][2], outs["generic"][2])
+            assert torch.equal(outs["dma"][0], outs["generic"][0]) and torch.equal(outs["dma"][1], outs["generic"][1]), f"case {ci}"
+    finally:
+        L.dcvic_conv_set_tuning(1, 1, 2)

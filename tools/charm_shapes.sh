@@ -1,6 +1,5 @@
-python tools/conv_layer_bench.py 96 192 128 128 32 1 10
-python tools/conv_layer_bench.py 192 96 128 128 32 1 10
-python tools/conv_layer_bench.py 512 1536 32 32 32 1 10
-python tools/conv_layer_bench.py 512 512 32 32 32 1 10
-python tools/conv_layer_bench.py 256 128 256 256 32 1 5
-python tools/conv_layer_bench.py 448 256 128 128 32 1 5
+for d in 0 1; do export DCVIC_CONV_DMA=$d; echo "== dma $d"
+python tools/conv_layer_bench.py 96 96 128 128 32 3 10
+python tools/conv_layer_bench.py 96 96 64 64 32 3 10
+python tools/conv_layer_bench.py 192 192 64 64 32 3 10
+done
