@@ -26,6 +26,39 @@ __device__ __forceinline__ double block_sum_d(double v, double* red) {
 
 __device__ __forceinline__ float std_cumulative(float x) { return 0.5f * erfcf(-0.70710678118654752440f * x); }
 
+// one element: symbolise / de-quantise, cdf index, likelihood; returns log(p) (0 when not wanted)
+__device__ __forceinline__ float gr_element(float yv, int sv, bool have_y, float m, float sg, const float* tab, int n_scales,
+                                            bool want_idx, bool want_p, float& yh, int& sym_o, int& ix_o, float& p_o) {
+    const float s = fmaxf(sg, 0.11f);
+    const float sym = have_y ? rintf(__fsub_rn(yv, m)) : (float)sv;
+    yh = __fadd_rn(sym, m);
+    sym_o = (int)sym;
+    if (want_idx) {
+        // index = (n - 1) - #{t < n - 1 : s <= tab[t]} = first t with tab[t] >= s (the table ascends), clipped to n - 1:
+        // a 6-step branchless binary search instead of 63 compares
+        int lo = 0, len = n_scales - 1;
+        while (len > 0) {
+            const int half = len >> 1;
+            const bool right = tab[lo + half] < s;
+            lo = right ? lo + half + 1 : lo;
+            len = right ? len - half - 1 : half;
+        }
+        ix_o = lo;
+    }
+    float lp = 0.f;
+    if (want_p) {
+        const float v = fabsf(__fsub_rn(yh, m));
+        const float up = std_cumulative((0.5f - v) / s);
+        const float lw = std_cumulative((-0.5f - v) / s);
+        p_o = fmaxf(up - lw, 1e-9f);
+        lp = logf(p_o);
+    }
+    return lp;
+}
+
+// VEC: every stream is 16-B aligned and the block spans are multiples of 4 -> float4 / int4 accesses, four elements per
+// lane and iteration (the kernel is a pure streaming op: 20-28 B per element)
+template <bool VEC>
 __global__ __launch_bounds__(256) void gaussian_rate_kernel(const float* __restrict__ y, long long y_bs,
                                                             const int32_t* __restrict__ sym_in, const float* __restrict__ mu,
                                                             const float* __restrict__ sigma, long long ms_bs,
@@ -42,29 +75,44 @@ __global__ __launch_bounds__(256) void gaussian_rate_kernel(const float* __restr
     double acc = 0.0;
     // block b of image n owns the contiguous span [b*span, (b+1)*span): the decomposition depends on CHW only,
     // so the per-image sum has one fixed order whatever the batch size
-    const long long span = (CHW + gridDim.x - 1) / gridDim.x;
+    long long span = (CHW + gridDim.x - 1) / gridDim.x;
+    if (VEC) span = (span + 3) & ~3ll;
     const long long i_end = min(CHW, (long long)(blockIdx.x + 1) * span);
-    for (long long i = (long long)blockIdx.x * span + threadIdx.x; i < i_end; i += blockDim.x) {
-        const float m = mu[n * ms_bs + i];
-        const float s = fmaxf(sigma[n * ms_bs + i], 0.11f);
-        float sym;
-        if (y) sym = rintf(__fsub_rn(y[n * y_bs + i], m));
-        else sym = (float)sym_in[n * si_bs + i];
-        const float yh = __fadd_rn(sym, m);
-        if (y_hat) y_hat[n * yh_bs + i] = yh;
-        if (sym_out) sym_out[n * si_bs + i] = (int32_t)sym;
-        if (index_out) {
-            int ix = n_scales - 1;
-            for (int t = 0; t < n_scales - 1; ++t) ix -= (s <= tab[t]) ? 1 : 0;
-            index_out[n * si_bs + i] = ix;
+    const bool want_p = lik_out || partial;
+    if (VEC) {
+        for (long long i = (long long)blockIdx.x * span + 4 * threadIdx.x; i < i_end; i += 4 * blockDim.x) {
+            const float4 m4 = *reinterpret_cast<const float4*>(mu + n * ms_bs + i);
+            const float4 s4 = *reinterpret_cast<const float4*>(sigma + n * ms_bs + i);
+            float4 y4 = make_float4(0.f, 0.f, 0.f, 0.f);
+            int4 q4 = make_int4(0, 0, 0, 0);
+            if (y) y4 = *reinterpret_cast<const float4*>(y + n * y_bs + i);
+            else q4 = *reinterpret_cast<const int4*>(sym_in + n * si_bs + i);
+            float4 yh4, p4 = make_float4(0.f, 0.f, 0.f, 0.f);
+            int4 so4, ix4 = make_int4(0, 0, 0, 0);
+            float lp = gr_element(y4.x, q4.x, y != nullptr, m4.x, s4.x, tab, n_scales, index_out != nullptr, want_p, yh4.x, so4.x, ix4.x, p4.x);
+            acc += (double)lp;
+            lp = gr_element(y4.y, q4.y, y != nullptr, m4.y, s4.y, tab, n_scales, index_out != nullptr, want_p, yh4.y, so4.y, ix4.y, p4.y);
+            acc += (double)lp;
+            lp = gr_element(y4.z, q4.z, y != nullptr, m4.z, s4.z, tab, n_scales, index_out != nullptr, want_p, yh4.z, so4.z, ix4.z, p4.z);
+            acc += (double)lp;
+            lp = gr_element(y4.w, q4.w, y != nullptr, m4.w, s4.w, tab, n_scales, index_out != nullptr, want_p, yh4.w, so4.w, ix4.w, p4.w);
+            acc += (double)lp;
+            if (y_hat) *reinterpret_cast<float4*>(y_hat + n * yh_bs + i) = yh4;
+            if (sym_out) *reinterpret_cast<int4*>(sym_out + n * si_bs + i) = so4;
+            if (index_out) *reinterpret_cast<int4*>(index_out + n * si_bs + i) = ix4;
+            if (lik_out) *reinterpret_cast<float4*>(lik_out + n * si_bs + i) = p4;
         }
-        if (lik_out || partial) {
-            const float v = fabsf(__fsub_rn(yh, m));
-            const float up = std_cumulative((0.5f - v) / s);
-            const float lo = std_cumulative((-0.5f - v) / s);
-            const float p = fmaxf(up - lo, 1e-9f);
+    } else {
+        for (long long i = (long long)blockIdx.x * span + threadIdx.x; i < i_end; i += blockDim.x) {
+            float yh, p = 0.f;
+            int so, ix = 0;
+            const float lp = gr_element(y ? y[n * y_bs + i] : 0.f, sym_in ? sym_in[n * si_bs + i] : 0, y != nullptr, mu[n * ms_bs + i],
+                                        sigma[n * ms_bs + i], tab, n_scales, index_out != nullptr, want_p, yh, so, ix, p);
+            if (y_hat) y_hat[n * yh_bs + i] = yh;
+            if (sym_out) sym_out[n * si_bs + i] = so;
+            if (index_out) index_out[n * si_bs + i] = ix;
             if (lik_out) lik_out[n * si_bs + i] = p;
-            acc += (double)logf(p);
+            acc += (double)lp;
         }
     }
     if (partial) {
@@ -99,8 +147,17 @@ extern "C" int dcvic_gaussian_rate_f32(const float* y, long long y_bs, const int
     DCVIC_CHECK_ARG(N <= 65535 && (!bits_out || N <= 1024), "gaussian_rate: batch too large (bits_out: <= 1024 images per call)");
     const int nb = dcvic_rate_blocks(CHW);
     dim3 grid(nb, N);
-    gaussian_rate_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(y, y_bs, sym_in, mu, sigma, ms_bs, scale_table, n_scales, y_hat,
-                                                              yh_bs, sym_out, index_out, si_bs, lik_out, bits_out ? partial_ws : nullptr, CHW);
+    auto al16 = [](const void* p) { return p == nullptr || (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+    // NOTE the vector form is chosen from CHW, strides and alignment only (never N): the reduction order of bits[n] is the
+    // same for every batch size of a given layout
+    const bool vec = (CHW & 3) == 0 && (ms_bs & 3) == 0 && (si_bs & 3) == 0 && (!y || (y_bs & 3) == 0) && (!y_hat || (yh_bs & 3) == 0) &&
+                     al16(y) && al16(sym_in) && al16(mu) && al16(sigma) && al16(y_hat) && al16(sym_out) && al16(index_out) && al16(lik_out);
+    if (vec)
+        gaussian_rate_kernel<true><<<grid, 256, 0, (hipStream_t)stream>>>(y, y_bs, sym_in, mu, sigma, ms_bs, scale_table, n_scales, y_hat,
+                                                                        yh_bs, sym_out, index_out, si_bs, lik_out, bits_out ? partial_ws : nullptr, CHW);
+    else
+        gaussian_rate_kernel<false><<<grid, 256, 0, (hipStream_t)stream>>>(y, y_bs, sym_in, mu, sigma, ms_bs, scale_table, n_scales, y_hat,
+                                                                         yh_bs, sym_out, index_out, si_bs, lik_out, bits_out ? partial_ws : nullptr, CHW);
     DCVIC_CHECK_LAUNCH("gaussian_rate");
     if (bits_out) {
         rate_finish_kernel<<<1, N, 0, (hipStream_t)stream>>>(partial_ws, nb, bits_out);
