@@ -144,6 +144,9 @@ __global__ __launch_bounds__(D_THREADS, 4) void conv3x3_dma_kernel(const ConvKAr
         for (int j = 0; j < NWJ; ++j) wp4[j] += wstep;
     };
 
+    // the workgroup's bias values go to LDS (read in the epilogue without touching vmcnt)
+    float* const sbias = smem + 2 * D_BUF;
+    if (tid < D_TC) sbias[tid] = K.bias ? K.bias[min(cotile * D_TC + tid, K.Cout - 1)] : 0.f;
     issue(0, 0);
     __syncthreads();
 
@@ -188,6 +191,57 @@ __global__ __launch_bounds__(D_THREADS, 4) void conv3x3_dma_kernel(const ConvKAr
 
     // ---- epilogue: bias -> act -> (+res) -> (affine) -> store  (same order as conv.hip)
     const long long HWo = (long long)K.Hfull * K.Wfull;
+    // Fast form for interior tiles without the affine: the residuals of the next 8-value sub-group are requested BEFORE
+    // the current sub-group's stores, so the wait for them is a counted vmcnt that leaves those stores in flight (vmcnt
+    // counts stores on gfx950: with loads and stores alternating batch by batch every load-wait drained the previous
+    // stores -- 87k / 139k cycles per workgroup, bias only / bias + residual).  Bias comes from LDS; residual and output
+    // share one 32-bit byte offset from scalar bases.
+    if (oy0 + D_TH <= K.Hout && ox0 + D_TW <= K.Wout && (cotile + 1) * D_TC <= K.Cout && !K.affs &&
+        (long long)K.Cout * HWo * 4 < (1ll << 32)) {
+        const char* const rb = reinterpret_cast<const char*>(K.res ? K.res + (long long)n * K.res_bs : nullptr);
+        char* const ob = reinterpret_cast<char*>(K.out + (long long)n * K.out_bs);
+        const bool has_res = K.res != nullptr;
+        const int act = K.act;
+        constexpr int NG = MT * NT;
+        constexpr int NS = 2 * NG, SB = 8;                                 // sub-groups of 8 values: register budget (128)
+        unsigned goff[NG];                                                 // byte offset of element r = 0 of group g
+        dcvic_static_for<0, NG>([&](auto g_) {
+            constexpr int g = decltype(g_)::value, mt = g % MT, nt = g / MT;
+            const int oy = oy0 + wn * NT + nt, ox = ox0 + lane_j;
+            const long long pix = (long long)(oy * K.osy + K.ooy) * K.Wfull + (ox * K.osx + K.oox);
+            goff[g] = (unsigned)(4 * ((long long)(cotile * D_TC + (wm * MT + mt) * 32 + 4 * lane_k) * HWo + pix));
+        });
+        const unsigned rstep = (unsigned)(4 * HWo);                        // one channel, in bytes
+        float rv[2][SB];
+        auto loads = [&](auto s_, float (&dst)[SB]) {
+            constexpr int sg = decltype(s_)::value, g = sg / 2, r0 = (sg & 1) * SB;
+            dcvic_static_for<0, SB>([&](auto r_) {
+                constexpr int r = r0 + decltype(r_)::value;
+                dst[r - r0] = *reinterpret_cast<const float*>(rb + (goff[g] + (unsigned)((r & 3) + 8 * (r >> 2)) * rstep));
+            });
+        };
+        if (has_res) loads(std::integral_constant<int, 0>{}, rv[0]);
+        dcvic_static_for<0, NS>([&](auto s_) {
+            constexpr int sg = decltype(s_)::value, g = sg / 2, r0 = (sg & 1) * SB, mt = g % MT;
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (sg + 1 < NS) { if (has_res) loads(std::integral_constant<int, sg + 1>{}, rv[(sg + 1) & 1]); }
+            __builtin_amdgcn_sched_barrier(0);
+            float v[SB];
+            dcvic_static_for<0, SB>([&](auto r_) {
+                constexpr int r = r0 + decltype(r_)::value;
+                float e = acc[mt][g / MT][r] + sbias[(wm * MT + mt) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lane_k];
+                e = dcvic_act(e, act);
+                if (has_res) e += rv[sg & 1][r - r0];
+                v[r - r0] = e;
+            });
+            __builtin_amdgcn_sched_barrier(0);
+            dcvic_static_for<0, SB>([&](auto r_) {
+                constexpr int r = r0 + decltype(r_)::value;
+                *reinterpret_cast<float*>(ob + (goff[g] + (unsigned)((r & 3) + 8 * (r >> 2)) * rstep)) = v[r - r0];
+            });
+        });
+        return;
+    }
     dcvic_epilogue_dispatch(K, [&](auto res_, auto aff_) {
         constexpr bool RES = decltype(res_)::value, AFF = decltype(aff_)::value;
         dcvic_static_for<0, NT>([&](auto nt_) {
@@ -211,7 +265,7 @@ static int launch_tap_dma(const ConvKArgs& A, hipStream_t st) {
     auto k = conv3x3_dma_kernel<TY, TX, SKC, TCV>;
     constexpr int PLANE = (D_TH + TY - 1) * (D_TW + TX - 1);
     constexpr int XS = ((SKC * PLANE + D_THREADS - 1) / D_THREADS) * D_THREADS;
-    const size_t lds = (size_t)2 * (XS + TY * TX * SKC * TCV) * sizeof(float);
+    const size_t lds = (size_t)(2 * (XS + TY * TX * SKC * TCV) + TCV) * sizeof(float);   // + the bias row
     if (!attr_set) {
         hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
