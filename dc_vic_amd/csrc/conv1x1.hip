@@ -104,6 +104,15 @@ __global__ __launch_bounds__(Q_THREADS, 4) void conv1x1_dma_kernel(const ConvKAr
         }
     };
 
+    // per-channel epilogue vectors of this workgroup go to LDS (bias, and the beta-FT scale / shift of image n): they are
+    // read in the epilogue without touching vmcnt
+    float* const sbias = smem + 2 * BUF;
+    if (tid < TCv) {
+        const int c = min(cotile * TCv + tid, K.Cout - 1);
+        sbias[tid] = K.bias ? K.bias[c] : 0.f;
+        sbias[TCv + tid] = K.affs ? K.affs[(long long)n * K.aff_bs + c] : 0.f;
+        sbias[2 * TCv + tid] = K.afft ? K.afft[(long long)n * K.aff_bs + c] : 0.f;
+    }
     issue(0, 0);
     __syncthreads();
 
@@ -143,6 +152,54 @@ __global__ __launch_bounds__(Q_THREADS, 4) void conv1x1_dma_kernel(const ConvKAr
     }
 
     // ---- epilogue: bias -> act -> (+res) -> (affine) -> store  (same order as conv.hip); output plane is flat
+    // Fast form for full tiles (see conv3x3.hip): per-channel vectors from LDS, residuals requested one 8-value sub-group
+    // ahead of the stores, one 32-bit byte offset shared by residual and output.
+    if (p0 + Q_P <= HW && (cotile + 1) * TCv <= K.Cout && (long long)K.Cout * HW * 4 < (1ll << 32)) {
+        const char* const rb = reinterpret_cast<const char*>(K.res ? K.res + (long long)n * K.res_bs : nullptr);
+        char* const ob = reinterpret_cast<char*>(K.out + (long long)n * K.out_bs);
+        const bool has_res = K.res != nullptr, has_bias = K.bias != nullptr, has_aff = K.affs != nullptr;
+        const int act = K.act;
+        constexpr int NG = MT * NT, NS = 2 * NG, SB = 8;
+        unsigned goff[NG];
+        dcvic_static_for<0, NG>([&](auto g_) {
+            constexpr int g = decltype(g_)::value, mt = g % MT, nt = g / MT;
+            const int pix = p0 + wn * (NT * 32) + nt * 32 + lane_j;
+            goff[g] = (unsigned)(4 * ((long long)(cotile * TCv + (wm * MT + mt) * 32 + 4 * lane_k) * HW + pix));
+        });
+        const unsigned rstep = (unsigned)(4 * HW);
+        float rv[2][SB];
+        auto loads = [&](auto s_, float (&dst)[SB]) {
+            constexpr int sg = decltype(s_)::value, g = sg / 2, r0 = (sg & 1) * SB;
+            dcvic_static_for<0, SB>([&](auto r_) {
+                constexpr int r = r0 + decltype(r_)::value;
+                dst[r - r0] = *reinterpret_cast<const float*>(rb + (goff[g] + (unsigned)((r & 3) + 8 * (r >> 2)) * rstep));
+            });
+        };
+        if (has_res) loads(std::integral_constant<int, 0>{}, rv[0]);
+        dcvic_static_for<0, NS>([&](auto s_) {
+            constexpr int sg = decltype(s_)::value, g = sg / 2, r0 = (sg & 1) * SB, mt = g % MT;
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (sg + 1 < NS) { if (has_res) loads(std::integral_constant<int, sg + 1>{}, rv[(sg + 1) & 1]); }
+            __builtin_amdgcn_sched_barrier(0);
+            float v[SB];
+            dcvic_static_for<0, SB>([&](auto r_) {
+                constexpr int r = r0 + decltype(r_)::value;
+                const int cl = (wm * MT + mt) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lane_k;
+                float e = acc[mt][g / MT][r];
+                if (has_bias) e += sbias[cl];
+                e = dcvic_act(e, act);
+                if (has_res) e += rv[sg & 1][r - r0];
+                if (has_aff) e = e * (1.f + sbias[TCv + cl]) + sbias[2 * TCv + cl];
+                v[r - r0] = e;
+            });
+            __builtin_amdgcn_sched_barrier(0);
+            dcvic_static_for<0, SB>([&](auto r_) {
+                constexpr int r = r0 + decltype(r_)::value;
+                *reinterpret_cast<float*>(ob + (goff[g] + (unsigned)((r & 3) + 8 * (r >> 2)) * rstep)) = v[r - r0];
+            });
+        });
+        return;
+    }
     dcvic_epilogue_dispatch(K, [&](auto res_, auto aff_) {
         constexpr bool RES = decltype(res_)::value, AFF = decltype(aff_)::value;
         dcvic_static_for<0, NT>([&](auto nt_) {
@@ -167,7 +224,7 @@ static int launch_1x1(const ConvKArgs& A, hipStream_t st) {
         hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
-    const size_t lds = (size_t)2 * (Q_CH * Q_P + Q_CH * TCv) * sizeof(float);
+    const size_t lds = (size_t)(2 * (Q_CH * Q_P + Q_CH * TCv) + 3 * TCv) * sizeof(float);   // + bias / scale / shift rows
     k<<<A.nblocks, Q_THREADS, lds, st>>>(A);
     DCVIC_CHECK_LAUNCH("conv1x1_dma");
     return DCVIC_OK;

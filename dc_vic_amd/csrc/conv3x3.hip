@@ -200,7 +200,7 @@ __global__ __launch_bounds__(D_THREADS, 4) void conv3x3_dma_kernel(const ConvKAr
         (long long)K.Cout * HWo * 4 < (1ll << 32)) {
         const char* const rb = reinterpret_cast<const char*>(K.res ? K.res + (long long)n * K.res_bs : nullptr);
         char* const ob = reinterpret_cast<char*>(K.out + (long long)n * K.out_bs);
-        const bool has_res = K.res != nullptr;
+        const bool has_res = K.res != nullptr, has_bias = K.bias != nullptr;
         const int act = K.act;
         constexpr int NG = MT * NT;
         constexpr int NS = 2 * NG, SB = 8;                                 // sub-groups of 8 values: register budget (128)
@@ -229,7 +229,8 @@ __global__ __launch_bounds__(D_THREADS, 4) void conv3x3_dma_kernel(const ConvKAr
             float v[SB];
             dcvic_static_for<0, SB>([&](auto r_) {
                 constexpr int r = r0 + decltype(r_)::value;
-                float e = acc[mt][g / MT][r] + sbias[(wm * MT + mt) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lane_k];
+                float e = acc[mt][g / MT][r];
+                if (has_bias) e += sbias[(wm * MT + mt) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lane_k];   // (no "+ 0": keeps -0)
                 e = dcvic_act(e, act);
                 if (has_res) e += rv[sg & 1][r - r0];
                 v[r - r0] = e;
