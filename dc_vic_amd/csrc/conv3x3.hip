@@ -186,7 +186,7 @@ __global__ __launch_bounds__(D_THREADS, 4) void conv3x3_dma_kernel(const ConvKAr
 #pragma unroll
             for (int i = 0; i < NT; ++i) b_cur[i] = b_nxt[i];
         }
-        __syncthreads();
+        if (stage + 1 < n_stages) __syncthreads();             // nothing reads the staging buffers after the last stage
     }
 
     // ---- epilogue: bias -> act -> (+res) -> (affine) -> store  (same order as conv.hip)
