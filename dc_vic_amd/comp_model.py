@@ -166,6 +166,10 @@ def build_trained_comp_model(opt, ckpt_path: str):
 
 def _starts(size: int, stride: int, patch: int, pre_div: bool) -> List[int]:
     """Window starts of the tiling branches (hyperprior_vic_model.py:197-213 / 420-436)."""
+    if size < patch:
+        # the reference loop would emit a negative start here (size - patch) and slice a wrapped, narrower window
+        raise ValueError(f"tiling (max(H, W) > {SPLIT_DECODE_RESOLUTION}) needs both padded sides >= {SPLIT_WINDOW_SIZE} px; "
+                         f"got a side of {size * (SPLIT_WINDOW_SIZE // patch)} px")
     out = []
     rng = range(size // stride + 1) if pre_div else range(0, size, stride)
     for i in rng:
@@ -530,7 +534,7 @@ class HyperpriorDualCondVicModel(HyperpriorVicModel):
         _mark("rans_encode_cpu")
         return dict(string_lists=string_lists, z_hat=e["z_hat"], y_hat=y_hat, z_likelihood=e["z_likelihood"],
                     y_likelihood=e["y_likelihood"], vq_indices=gt_vq_indices, y=y, z=e["z"], y_symbols=e["symbols"],
-                    y_indexes=e["indexes"], z_symbols=e["z_symbols"],
+                    y_indexes=e["indexes"], z_symbols=e["z_symbols"], mu=e["mu"], sigma=e["sigma"],
                     pred_y_bit=bits_y, pred_z_bit=bits_z, pred_y_bpp=bits_y / (H * W), pred_z_bpp=bits_z / (H * W))
 
     @torch.no_grad()
@@ -544,6 +548,7 @@ class HyperpriorDualCondVicModel(HyperpriorVicModel):
             "pred_y_bit": float(r["pred_y_bit"][0]), "pred_y_bpp": float(r["pred_y_bpp"][0]),
             "pred_z_bit": float(r["pred_z_bit"][0]), "pred_z_bpp": float(r["pred_z_bpp"][0]),
             "vq_indices": r["vq_indices"], "y_symbols": r["y_symbols"], "y_indexes": r["y_indexes"], "z_symbols": r["z_symbols"],
+            "y": r["y"], "z": r["z"], "mu": r["mu"], "sigma": r["sigma"],
         }
 
     # ------------------------------------------------------------------ decompress (389-440)

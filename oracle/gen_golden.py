@@ -7,8 +7,21 @@ dc_vic_amd.synth weights into them with strict=True, runs each stage on seeded i
 inputs/outputs as small fixtures.  The fixtures are data (inputs + expected outputs + the
 reference's state-dict key/shape manifest); no reference source is copied.
 
-CompressAI-dependent pieces (entropy models, rANS, CHARM wrapper, comp_model classes) cannot be
-imported -> no fixture -> "parity unpinned" for them.
+CompressAI-dependent pieces (entropy models, rANS, comp_model classes) cannot be imported -> no
+fixture -> "parity unpinned" for them.
+
+CHARM (tests/golden/charm.npz): minnen20_charm_context_model.py imports two compressai NAMES at
+module level (a type annotation and the rANS decoder class used only by forward_decompress);
+ref_loader.install_compressai_names() supplies name-only placeholders that raise when used.  The
+fixture runs the reference's own `Minnen20CharmContextModel.forward(y, hyper_out, em,
+is_train=False, calc_q_likelihood=False)` (minnen20_charm_context_model.py:70-119) where the
+entropy-model callable is supplied HERE, not by the reference:
+        em(y_slice, cat[mu, sigma], is_train) = (torch.round(y_slice - mu) + mu, ones_like(y_slice))
+i.e. the eval-mode mean-shifted rounding the wrapper documents (ste_gaussian_conditional.py:22-23:
+`quantize(y, 'dequantize', means)`); the likelihood output is a constant and is not a fixture.
+What this pins: the slice wiring (support = first min(i, 4) decoded slices, channel order of the
+concatenations, mu/sigma/LRP transforms, 0.5 tanh) and all 54 conv layers.  The Gaussian
+likelihood / cdf-index arithmetic (a11) stays parity-unpinned.
 """
 from __future__ import annotations
 
@@ -66,6 +79,9 @@ def build_reference_modules():
         mods["hyperdecoder"] = mk(h.Minnen20HyperDecoder, "hyperdecoder")
         mods["vq_estimator"] = mk(s.DualBlockSwinVqEstimator, "vq_estimator")
         mods["fusion_module"] = f.VqDecFusionModule(**sub["fusion_module"])
+        ref_loader.install_compressai_names()
+        c = ref_loader.ref("src.models.subnet.context_model.minnen20_charm_context_model")
+        mods["context_model"] = mk(c.Minnen20CharmContextModel, "context_model")
     for mod in mods.values():
         mod.eval()
     return mods, top
@@ -106,14 +122,44 @@ def summ(t: torch.Tensor):
     return np.array([t.sum().item(), t.abs().sum().item(), (t * t).sum().item()], dtype=np.float64)
 
 
+def gen_charm(mods):
+    """a10: the reference's Minnen20CharmContextModel.forward with the stated rounding callable (module docstring)."""
+    cm = mods["context_model"]
+    C = {}
+    for tag, shp, s0 in (("c1", (2, 8, 12), 31), ("c2", (1, 16, 16), 41)):
+        N, H, W = shp
+        y = rnd((N, 192, H, W), s0, 1.5)
+        hyper = rnd((N, 256, H, W), s0 + 1, 1.0)
+        cap = {"mu": {}, "sigma": {}, "lrp": {}}
+        hooks = []
+        for kind, lst in (("mu", cm.mean_slice_transforms), ("sigma", cm.scale_slice_transforms), ("lrp", cm.lrp_slice_transforms)):
+            for i, t in enumerate(lst):
+                hooks.append(t.register_forward_hook(lambda m, a, o, kind=kind, i=i: cap[kind].__setitem__(i, o.detach().clone())))
+
+        def em(y_slice, params, is_train):
+            assert is_train is False
+            mu, _ = params.chunk(2, 1)
+            return torch.round(y_slice - mu) + mu, torch.ones_like(y_slice)
+
+        y_hat, lik = cm(y, hyper, em, is_train=False, calc_q_likelihood=False)
+        for h in hooks:
+            h.remove()
+        assert torch.all(lik == 1)
+        C[f"{tag}_y"] = y.numpy(); C[f"{tag}_hyper_out"] = hyper.numpy(); C[f"{tag}_y_hat"] = y_hat.numpy()
+        for kind in cap:
+            C[f"{tag}_{kind}"] = torch.cat([cap[kind][i] for i in range(cm.num_slices)], dim=1).numpy()
+    np.savez_compressed(os.path.join(OUT, "charm.npz"), **C)
+
+
 @torch.no_grad()
 def main():
     torch.set_num_threads(8)
     os.makedirs(OUT, exist_ok=True)
     mods, top = build_reference_modules()
     man = manifest_of(mods)
-    with open(os.path.join(OUT, "state_dict_manifest.json"), "w") as f:
-        json.dump(man, f, indent=0, sort_keys=True)
+    for path in (os.path.join(OUT, "state_dict_manifest.json"), os.path.join(ROOT, "dc_vic_amd", "manifest", "state_dict_manifest.json")):
+        with open(path, "w") as f:
+            json.dump(man, f, indent=0, sort_keys=True)
     load_synth(mods, man)
     G = {}
     br, bv = top["model"]["selected_beta_rate"], top["model"]["selected_beta_vq"]
@@ -186,6 +232,8 @@ def main():
     out_plain = dec(lat)
     G["a17p_out_ds"] = out_plain[:, :, ::4, ::4].numpy(); G["a17p_out_sum"] = summ(out_plain)
     np.savez_compressed(os.path.join(OUT, "stages.npz"), **G)
+
+    gen_charm(mods)
 
     # --- a13 wire format from the reference's own codec_utils
     cu = ref_loader.ref("src.utils.codec_utils")

@@ -17,8 +17,18 @@ provide three NON-ARITHMETIC helper stand-ins:
       - DropPath: never instantiated (drop_path=0. -> nn.Identity in
         swinir_layers.py:193)
 None of them participates in a forward pass.  CompressAI-dependent files
-(src/models/comp_model/*, entropy_model/*, minnen20_charm_context_model.py)
-are NOT imported: they stay "parity unpinned" (SURVEY 8c).
+(src/models/comp_model/*, entropy_model/*) are NOT imported: they stay "parity
+unpinned" (SURVEY 8c).
+
+`install_compressai_names()` (used only for the CHARM fixture) additionally
+registers NAME-ONLY placeholders for the two identifiers that
+minnen20_charm_context_model.py:12-13 imports at module level:
+  * compressai.ans.RansDecoder            - only instantiated in forward_decompress (:179)
+  * compressai.entropy_models.GaussianConditional - only a type annotation (:74, :124, :173)
+Both placeholders raise if anything tries to use them, so no CompressAI
+arithmetic is faked: the fixture drives `forward()` only, whose conv / cat /
+tanh arithmetic is plain torch, with the entropy-model callable passed in by
+gen_golden.py and stated in the fixture's docstring.
 """
 import importlib
 import os
@@ -101,6 +111,28 @@ def install():
     ]:
         if name not in sys.modules:
             _pkg(name, os.path.join(REF, *name.split(".")))
+
+
+def install_compressai_names():
+    """Name-only placeholders for `from compressai.ans import RansDecoder` and `from compressai.entropy_models
+    import GaussianConditional` (minnen20_charm_context_model.py:12-13).  Using either raises."""
+    if "compressai" in sys.modules:
+        return
+
+    class _NameOnly:
+        def __init__(self, *a, **k):
+            raise RuntimeError("compressai is not installed: this is a name-only placeholder (oracle/ref_loader.py)")
+
+    ca = types.ModuleType("compressai")
+    ans = types.ModuleType("compressai.ans")
+    em = types.ModuleType("compressai.entropy_models")
+    ans.RansDecoder = type("RansDecoder", (_NameOnly,), {})
+    em.GaussianConditional = type("GaussianConditional", (_NameOnly,), {})
+    ca.ans, ca.entropy_models = ans, em
+    ca.__dcvic_name_only__ = True
+    sys.modules["compressai"] = ca
+    sys.modules["compressai.ans"] = ans
+    sys.modules["compressai.entropy_models"] = em
 
 
 def ref(modname):

@@ -28,7 +28,42 @@ def golden():
 
 
 @pytest.fixture(scope="session")
+def charm_golden():
+    import numpy as np
+    return np.load(os.path.join(GOLDEN, "charm.npz"))
+
+
+@pytest.fixture(scope="session")
 def synth_sd(manifest):
     """Full synthetic state dict: reference-manifest tensors + the CompressAI-side ones."""
     from dc_vic_amd.synth import full_synth_state_dict
     return full_synth_state_dict(seed=1234)
+
+
+@pytest.fixture(scope="session")
+def oracle(synth_sd):
+    from oracle.dcvic_oracle import Oracle
+    return Oracle(synth_sd)
+
+
+@pytest.fixture(scope="session")
+def oracle_compress(oracle):
+    """Oracle.compress results cached per (image key, quality) for the whole session (a 512x768 pass costs ~15 s of CPU)."""
+    cache = {}
+
+    def get(key, x, q):
+        k = (key, q)
+        if k not in cache:
+            cache[k] = oracle.compress(x, q)
+        return cache[k]
+    return get
+
+
+def demo_image(name):
+    """The reference's demo_images/*.png (data fixtures) as the CLI loads them: ToTensor + Normalize(.5, .5), compress.py:57-60."""
+    import numpy as np
+    import torch
+    from PIL import Image
+    a = np.asarray(Image.open(os.path.join(GOLDEN, "demo_images", name)).convert("RGB"), dtype=np.uint8)
+    x = torch.from_numpy(a.copy()).permute(2, 0, 1).float().div(255.0)
+    return ((x - 0.5) / 0.5).unsqueeze(0)

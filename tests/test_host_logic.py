@@ -98,7 +98,7 @@ def test_state_dict_layout_matches_reference(cpu_model, manifest):
     for k, (shape, dtype) in manifest.items():
         assert k in sd, k
         assert list(sd[k].shape) == shape, k
-    extra = [k for k in sd if k not in manifest and not k.startswith(("context_model.", "entropy_model_z.", "entropy_model_y."))]
+    extra = [k for k in sd if k not in manifest and not k.startswith(("entropy_model_z.", "entropy_model_y."))]
     assert extra == []
     for k in ["entropy_model_z._matrix0", "entropy_model_z._bias4", "entropy_model_z._factor3", "entropy_model_z.quantiles",
               "entropy_model_z._quantized_cdf", "entropy_model_z._offset", "entropy_model_z._cdf_length",

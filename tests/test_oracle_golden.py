@@ -105,6 +105,29 @@ def test_fusion_decoder(golden, synth_sd):
     close(plain[:, :, ::4, ::4], golden["a17p_out_ds"], rtol=1e-3, atol=1e-3)
 
 
+@pytest.mark.parametrize("tag", ["c1", "c2"])
+def test_charm_vs_reference_module(charm_golden, synth_sd, tag):
+    """a10: oracle charm_forward vs the reference's own Minnen20CharmContextModel.forward (fixture docstring in
+    oracle/gen_golden.py: em = (round(y - mu) + mu, ones)).  Same torch CPU ops -> every slice's mu / sigma / LRP
+    and the final y_hat agree to reduction-order slack; the rounding decisions must be identical."""
+    G = charm_golden
+    r = O.charm_forward(synth_sd, t(G[f"{tag}_y"]), t(G[f"{tag}_hyper_out"]))
+    close(r["mu"], G[f"{tag}_mu"]); close(r["sigma"], G[f"{tag}_sigma"])
+    sym_ref = np.round(G[f"{tag}_y"] - G[f"{tag}_mu"])
+    assert np.array_equal(r["symbols"].numpy(), sym_ref.astype(np.int32))
+    close(r["lrp"], 0.5 * np.tanh(G[f"{tag}_lrp"].astype(np.float64)))
+    close(r["y_hat"], G[f"{tag}_y_hat"])
+
+
+def test_charm_manifest_matches_reference_module(manifest):
+    """The context-model keys/shapes the synthetic-weight generator derives from the YAML equal the reference
+    module's own state dict (now part of the reference-produced manifest)."""
+    from dc_vic_amd.synth import charm_manifest
+    cm = charm_manifest()
+    ref = {k: v for k, v in manifest.items() if k.startswith("context_model.")}
+    assert len(ref) == 108 and cm == ref
+
+
 def test_wire_format():
     with open(os.path.join(os.path.dirname(__file__), "golden", "wire_format.json")) as f:
         W = json.load(f)
