@@ -85,6 +85,8 @@ def main():
         raise SystemExit("bench.py needs a HIP device (the path has no CPU fallback)")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    from dc_vic_amd.parallel import pin_rank_cpus
+    cpus = pin_rank_cpus()            # the ranks of a node share its cores: each takes its slice (rANS threads)
     dist = None
     if world > 1 or "TORCHELASTIC_RUN_ID" in os.environ or os.environ.get("DCVIC_FORCE_DIST") == "1":
         # launched by torch.distributed.run: take the collective path even at world size 1 (same code as N > 1)
@@ -107,12 +109,16 @@ def main():
     IH, IW = a.height, a.width
     x = (torch.rand((B, 3, IH, IW), generator=g) * 2 - 1).to(dev)
 
+    gather_s = [0.0]
+
     def step():
         r = model.compress_batch(x, a.quality)
         imgs, _, _ = model.decompress_batch(r["string_lists"])
         real_bits = np.array([8.0 * sum(len(s) for s in sl) + 32 * 3 for sl in r["string_lists"]])   # + 3 uint32 length prefixes
         table = np.stack([real_bits, r["pred_y_bit"] + r["pred_z_bit"]], axis=1)
-        table = gather_rate_table(table, dist, dev)
+        tg = time.perf_counter()
+        table = gather_rate_table(table, dist, dev)       # the only collective: a few KB over RCCL
+        gather_s[0] += time.perf_counter() - tg
         return imgs, table
 
     def sync():
@@ -132,9 +138,12 @@ def main():
     log(f"model ready, {a.warmup} warm-up step(s) in {time.perf_counter() - t_w:.2f}s")
     if not a.no_kernel_events:
         ops.kernel_events_start()
+    gather_s[0] = 0.0
     t0 = time.perf_counter()
     for _ in range(a.steps):
         imgs, table = step()
+    torch.cuda.synchronize(dev)
+    dt_local = time.perf_counter() - t0       # this rank's own time (before the barrier): shows load imbalance
     sync()
     dt = time.perf_counter() - t0
     log(f"{a.steps} timed step(s) in {dt:.2f}s")
@@ -164,10 +173,17 @@ def main():
         stage_ms["sum"] = sum(stage_ms.values())
     sync()
 
+    per_rank = [[1e3 * dt_local / a.steps, 1e3 * gather_s[0] / a.steps, float(len(cpus))]]
     if dist is not None:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+        mine = torch.tensor(per_rank[0], dtype=torch.float64, device=dev)
+        parts = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(parts, mine)
+        per_rank = [p_.tolist() for p_ in parts]
+    for r_, (ms_, g_, c_) in enumerate(per_rank):
+        log(f"rank {r_}: {ms_:.1f} ms/step (own clock), rate-table all_gather {g_:.2f} ms/step, {int(c_)} host cores")
 
     if rank == 0:
         n_img = world * B * a.steps
@@ -181,9 +197,13 @@ def main():
                                    "compress_batch+decompress_batch through real rANS bytes, synthetic weights",
                        "batch_per_gpu": B, "quality": a.quality, "image": f"{IH}x{IW}", "parallelism": f"dp{world} (images sharded, RCCL all_gather of the rate table)"},
             "avg_bpp": avg_bpp,
+            "per_rank_ms_per_step": [p_[0] for p_ in per_rank], "per_rank_gather_ms_per_step": [p_[1] for p_ in per_rank],
+            "per_rank_host_cores": [int(p_[2]) for p_ in per_rank],
             "stage_ms_per_step": stage_ms,
             "avg_pred_bpp": float(table[:, 1].mean() / (IH * IW)),
-            "end_to_end_frac_of_f32_mfma_peak": value / world * GFLOP_PER_IMAGE * (IH * IW) / 65536.0 / 1e3 / PEAK_F32_MFMA_TFLOPS,
+            # ALGORITHMIC flop (1 009.6 GF per 256^2 image, upsample+conv counted at full 3x3 cost although the
+            # sub-pixel form executes 4/9 of it) / wall time / peak -- an end-to-end figure, not a kernel utilisation
+            "end_to_end_algorithmic_flop_frac_of_f32_mfma_peak": value / world * GFLOP_PER_IMAGE * (IH * IW) / 65536.0 / 1e3 / PEAK_F32_MFMA_TFLOPS,
         }
         if ev:
             k = max(ev.values(), key=lambda d: d["time_s"])

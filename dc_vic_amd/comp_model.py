@@ -187,6 +187,9 @@ class BaseModel(nn.Module):
         super().__init__()
         self.opt = opt
         self.device = _get(opt, "device", "cuda:0")
+        if str(self.device).startswith("cuda") and torch.cuda.is_available():
+            # the C-ABI kernels launch on the current device's current stream (`-d cuda:1` must make cuda:1 current)
+            torch.cuda.set_device(torch.device(self.device))
         self.convert_img_range = bool(_get(opt, "convert_img_range_to_01", False))
         if self.convert_img_range:
             raise NotImplementedError("convert_img_range_to_01 is not used by the DC-VIC configs")

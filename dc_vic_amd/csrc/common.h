@@ -6,6 +6,8 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <atomic>
+
 #include "dcvic.h"
 
 void dcvic_set_error(const char* fmt, ...);
@@ -38,5 +40,16 @@ __device__ __forceinline__ float dcvic_act(float v, int act) {
         default: return v;
     }
 }
+
+// Function attributes (dynamic-LDS limit) are per device: returns true the first time the calling site runs
+// on the current HIP device (bit per ordinal in a site-local mask; devices >= 32 simply re-apply every call).
+static inline bool dcvic_first_use_on_device(std::atomic<unsigned>& mask) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 32) return true;
+    const unsigned bit = 1u << dev;
+    return (mask.fetch_or(bit, std::memory_order_acq_rel) & bit) == 0;
+}
+// Compute units of the current HIP device (cached per ordinal).
+int dcvic_num_cu();
 
 static inline int dcvic_cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }

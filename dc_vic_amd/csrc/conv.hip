@@ -255,12 +255,15 @@ static const int kClassNP[4] = {3, 3, 4, 2};
 static const int kClassP[4][4] = {{256, 128, 64, 0}, {256, 128, 64, 0}, {256, 128, 64, 32}, {256, 128, 0, 0}};
 static inline int cfg_TC(int c) { return kClassTC[c]; }
 
-static int g_num_cu = 0;
+// No process-global mutable state: the scheduling switches and the last-variant report are PER CALLING THREAD (debug /
+// test aids that never change results), the CU count and kernel attributes are per device.
+static thread_local int g_num_cu = 0;          // CUs of the device current at the last entry-point call of this thread
 static thread_local int g_last_variant = -1;   // 9000: conv3x3_dma_kernel; else cls*1000 + P (+1 when UPS)
-static int g_use_dma = 1;   // DCVIC_CONV_DMA=0 forces the generic kernel (A/B comparisons, debugging)
-static int g_use_async = 1; // DCVIC_CONV_ASYNC=0 disables conv_async.hip
-static int g_async_fill = 2; // async twin when workgroups <= g_async_fill x CUs (DCVIC_CONV_ASYNC_FILL)
-static int g_use_async16 = 1; // DCVIC_CONV_ASYNC16=0: keep the 32x32x2 build of the async twin for the small tiles too
+static thread_local int g_tuning_init = 0;
+static thread_local int g_use_dma = 1;   // DCVIC_CONV_DMA=0 forces the generic kernel (A/B comparisons, debugging)
+static thread_local int g_use_async = 1; // DCVIC_CONV_ASYNC=0 disables conv_async.hip
+static thread_local int g_async_fill = 2; // async twin when workgroups <= g_async_fill x CUs (DCVIC_CONV_ASYNC_FILL)
+static thread_local int g_use_async16 = 1; // DCVIC_CONV_ASYNC16=0: keep the 32x32x2 build of the async twin for the small tiles too
 
 static int tile_width_log(int Wout) {
     int TWlog = 5;
@@ -372,13 +375,12 @@ extern "C" int dcvic_conv_pack_f32(const dcvic_conv_desc* d, const float* w, flo
 
 template <int MT, int NT, int WM, int WN>
 static int launch_variant(const ConvKArgs& K, bool ups, size_t lds, hipStream_t st) {
-    static bool attr_set = false;
+    static std::atomic<unsigned> attr_mask{0};
     auto k0 = conv_mfma_kernel<MT, NT, WM, WN, false>;
     auto k1 = conv_mfma_kernel<MT, NT, WM, WN, true>;
-    if (!attr_set) {
+    if (dcvic_first_use_on_device(attr_mask)) {
         hipFuncSetAttribute(reinterpret_cast<const void*>(k0), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         hipFuncSetAttribute(reinterpret_cast<const void*>(k1), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_set = true;
     }
     if (ups) k1<<<K.nblocks, NTHREADS, lds, st>>>(K);
     else k0<<<K.nblocks, NTHREADS, lds, st>>>(K);
@@ -387,7 +389,9 @@ static int launch_variant(const ConvKArgs& K, bool ups, size_t lds, hipStream_t 
 }
 
 static void init_num_cu() {
-    if (g_num_cu == 0) {
+    g_num_cu = dcvic_num_cu();
+    if (!g_tuning_init) {
+        g_tuning_init = 1;
         const char* e = getenv("DCVIC_CONV_DMA");
         if (e && e[0] == '0') g_use_dma = 0;
         e = getenv("DCVIC_CONV_ASYNC");
@@ -396,9 +400,6 @@ static void init_num_cu() {
         if (e && e[0] == '0') g_use_async16 = 0;
         e = getenv("DCVIC_CONV_ASYNC_FILL");
         if (e && atoi(e) > 0) g_async_fill = atoi(e);
-        int dev = 0, cu = 0;
-        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cu > 0) g_num_cu = cu;
-        else g_num_cu = 256;
     }
 }
 

@@ -218,11 +218,10 @@ __global__ __launch_bounds__(Q_THREADS, 4) void conv1x1_dma_kernel(const ConvKAr
 
 template <int TCv>
 static int launch_1x1(const ConvKArgs& A, hipStream_t st) {
-    static bool attr_set = false;
+    static std::atomic<unsigned> attr_mask{0};
     auto k = conv1x1_dma_kernel<TCv>;
-    if (!attr_set) {
+    if (dcvic_first_use_on_device(attr_mask)) {
         hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_set = true;
     }
     const size_t lds = (size_t)(2 * (Q_CH * Q_P + Q_CH * TCv) + 3 * TCv) * sizeof(float);   // + bias / scale / shift rows
     k<<<A.nblocks, Q_THREADS, lds, st>>>(A);

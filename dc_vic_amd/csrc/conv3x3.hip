@@ -262,14 +262,13 @@ __global__ __launch_bounds__(D_THREADS, 4) void conv3x3_dma_kernel(const ConvKAr
 
 template <int TY, int TX, int SKC, int TCV>
 static int launch_tap_dma(const ConvKArgs& A, hipStream_t st) {
-    static bool attr_set = false;
+    static std::atomic<unsigned> attr_mask{0};
     auto k = conv3x3_dma_kernel<TY, TX, SKC, TCV>;
     constexpr int PLANE = (D_TH + TY - 1) * (D_TW + TX - 1);
     constexpr int XS = ((SKC * PLANE + D_THREADS - 1) / D_THREADS) * D_THREADS;
     const size_t lds = (size_t)(2 * (XS + TY * TX * SKC * TCV) + TCV) * sizeof(float);   // + the bias row
-    if (!attr_set) {
+    if (dcvic_first_use_on_device(attr_mask)) {
         hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_set = true;
     }
     k<<<A.nblocks, D_THREADS, lds, st>>>(A);
     DCVIC_CHECK_LAUNCH("conv_tap_dma");

@@ -314,13 +314,12 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_mfma_async16_kernel(const Co
 
 template <int M16, int N16, int WM, int WN>
 static int launch_async16(const ConvKArgs& K, int xs_floats, int ws_floats, hipStream_t st) {
-    static bool attr_set = false;
+    static std::atomic<unsigned> attr_mask{0};
     auto k1 = conv_mfma_async16_kernel<M16, N16, WM, WN, false>;
     auto k2 = conv_mfma_async16_kernel<M16, N16, WM, WN, true>;
-    if (!attr_set) {
+    if (dcvic_first_use_on_device(attr_mask)) {
         hipFuncSetAttribute(reinterpret_cast<const void*>(k1), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         hipFuncSetAttribute(reinterpret_cast<const void*>(k2), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_set = true;
     }
     const size_t lds = (size_t)2 * (xs_floats + ws_floats) * sizeof(float);
     if (K.halves == 2) k2<<<K.nblocks, NTHREADS, lds, st>>>(K, xs_floats, ws_floats);

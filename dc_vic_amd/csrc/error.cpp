@@ -24,3 +24,17 @@ extern "C" int dcvic_device_info(int* n_cu, int* lds_bytes) {
     if (lds_bytes) *lds_bytes = (int)p.maxSharedMemoryPerMultiProcessor;
     return DCVIC_OK;
 }
+
+int dcvic_num_cu() {
+    static std::atomic<int> cache[32];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 256;
+    if (dev >= 0 && dev < 32) {
+        const int c = cache[dev].load(std::memory_order_relaxed);
+        if (c > 0) return c;
+    }
+    int cu = 0;
+    if (hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cu <= 0) cu = 256;
+    if (dev >= 0 && dev < 32) cache[dev].store(cu, std::memory_order_relaxed);
+    return cu;
+}

@@ -39,14 +39,13 @@ def get_scale_table(min_: float = SCALES_MIN, max_: float = SCALES_MAX, levels: 
 
 
 def host_threads() -> int:
+    """rANS coder threads of this rank: min(16, its share of the host cores) -- affinity // LOCAL_WORLD_SIZE, so the
+    N ranks of a node together stay within the machine (DCVIC_HOST_THREADS overrides)."""
     env = os.environ.get("DCVIC_HOST_THREADS")
     if env:
         return max(1, int(env))
-    try:
-        n = len(os.sched_getaffinity(0))
-    except AttributeError:
-        n = os.cpu_count() or 1
-    return max(1, min(16, n))
+    from .parallel import host_core_budget
+    return max(1, min(16, host_core_budget()))
 
 
 def _pmf_to_cdf(pmf: Tensor, tail_mass: Tensor, pmf_length: Tensor, max_length: int) -> np.ndarray:

@@ -35,11 +35,9 @@ def encode_png_u8(path: str, u8_hwc: np.ndarray) -> None:
 
 
 def default_workers() -> int:
-    try:
-        n = len(os.sched_getaffinity(0))
-    except AttributeError:
-        n = os.cpu_count() or 1
-    return max(1, min(8, n))
+    """PNG worker threads of this rank: min(8, its share of the host cores) (affinity // LOCAL_WORLD_SIZE)."""
+    from .parallel import host_core_budget
+    return max(1, min(8, host_core_budget()))
 
 
 class BatchPrefetcher:

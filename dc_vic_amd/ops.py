@@ -24,6 +24,11 @@ def _stream() -> C.c_void_p:
 def _chk4(t: Tensor, name: str = "tensor") -> Tuple[int, int, int, int]:
     if t.dtype != torch.float32 or not t.is_cuda or t.dim() != 4:
         raise ValueError(f"{name}: need a 4-D fp32 device tensor, got {t.dtype} {tuple(t.shape)} {t.device}")
+    if t.device.index != torch.cuda.current_device():
+        # kernels launch on the CURRENT device's current stream: a tensor of another GPU would be dereferenced by the
+        # wrong device.  BaseModel.__init__ / the CLIs make the model's device current; anything else must too.
+        raise ValueError(f"{name} lives on {t.device} but the current HIP device is cuda:{torch.cuda.current_device()}: "
+                         f"call torch.cuda.set_device({t.device.index}) (or run under `with torch.cuda.device(...)`) first")
     N, Cc, H, W = t.shape
     st = t.stride()
     if W > 1 and st[3] != 1 or (H > 1 and st[2] != W) or (Cc > 1 and st[1] != H * W):

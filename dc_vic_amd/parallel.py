@@ -5,10 +5,56 @@ ROCm, "gloo" on CPU for tests).  The reference is single-process (README.md:64-6
 """
 from __future__ import annotations
 
+import os
 from typing import List, Optional, Sequence
 
 import numpy as np
 import torch
+
+
+# ------------------------------------------------------------------------------------------- host-core budget
+# N ranks of one node share the host's cores: the rANS coder threads and the PNG workers of every rank
+# together must not exceed them, so each rank gets affinity // LOCAL_WORLD_SIZE cores and may pin itself to its slice.
+def _affinity() -> List[int]:
+    try:
+        return sorted(os.sched_getaffinity(0))
+    except AttributeError:
+        return list(range(os.cpu_count() or 1))
+
+
+def local_world_size() -> int:
+    return max(1, int(os.environ.get("LOCAL_WORLD_SIZE", os.environ.get("WORLD_SIZE", "1")) or 1))
+
+
+def host_core_budget() -> int:
+    """Cores this rank may use: its share of the process affinity (already the share after pin_rank_cpus())."""
+    n = len(_affinity())
+    if os.environ.get("DCVIC_CPUS_PINNED") == "1":
+        return max(1, n)
+    return max(1, n // local_world_size())
+
+
+def rank_cpu_slice(local_rank: int, local_world: int, cpus: Optional[Sequence[int]] = None) -> List[int]:
+    """Contiguous slice of the affinity list for a local rank (disjoint across ranks, all cores used when divisible)."""
+    cpus = list(_affinity() if cpus is None else cpus)
+    k = max(1, len(cpus) // max(1, local_world))
+    lo = (local_rank * k) % len(cpus)
+    return cpus[lo:lo + k] or cpus[:1]
+
+
+def pin_rank_cpus() -> List[int]:
+    """Pin this process (and the threads it creates later) to its rank's core slice.  No-op for a single local rank or
+    when DCVIC_PIN_CPUS=0.  Returns the CPU list in effect."""
+    lw = local_world_size()
+    if lw <= 1 or os.environ.get("DCVIC_PIN_CPUS", "1") == "0" or os.environ.get("DCVIC_CPUS_PINNED") == "1":
+        return _affinity()
+    sl = rank_cpu_slice(int(os.environ.get("LOCAL_RANK", "0")), lw)
+    try:
+        os.sched_setaffinity(0, sl)
+        os.environ["DCVIC_CPUS_PINNED"] = "1"
+    except (AttributeError, OSError):
+        pass
+    return _affinity()
 
 
 def shard_indices(n_items: int, rank: int, world: int, costs: Optional[Sequence[float]] = None) -> List[int]:

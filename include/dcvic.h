@@ -130,7 +130,8 @@ int dcvic_conv_select_class(const dcvic_conv_desc* d, int N, int Hout, int Wout)
 int dcvic_conv_last_variant(void);
 /* Scheduling switches (A/B runs, tests): use_dma 0|1, use_async 0|1|2 (2 = async twin without its 16x16x4 build), async_fill = the async twin is used when a launch
  * has <= async_fill x CUs workgroups; -1 keeps a value.  Never changes results: every kernel computes the same
- * reduction order.  Process-wide; returns DCVIC_OK. */
+ * reduction order.  Debug / test aid, state PER CALLING THREAD (like dcvic_conv_last_variant); defaults come from
+ * DCVIC_CONV_DMA / DCVIC_CONV_ASYNC / DCVIC_CONV_ASYNC16 / DCVIC_CONV_ASYNC_FILL, read once per thread.  Returns DCVIC_OK. */
 int dcvic_conv_set_tuning(int use_dma, int use_async, int async_fill);
 size_t dcvic_conv_packed_bytes(const dcvic_conv_desc* d);
 int dcvic_conv_pack_f32(const dcvic_conv_desc* d, const float* w, float* packed, void* stream);

@@ -33,7 +33,7 @@ from dc_vic_amd import BaseConfig, build_comp_model  # noqa: E402
 from dc_vic_amd.codec_utils import load_byte_strings, save_byte_strings  # noqa: E402
 from dc_vic_amd.io_pipeline import AsyncWriter, BatchPrefetcher, encode_png_u8  # noqa: E402
 from dc_vic_amd.options import compress_arg_parser  # noqa: E402
-from dc_vic_amd.parallel import gather_rate_table, shard_indices  # noqa: E402
+from dc_vic_amd.parallel import gather_rate_table, pin_rank_cpus, shard_indices  # noqa: E402
 
 COLUMNS = ["img_name", "header_bit", "z_bit", "y_bit", "real_bit", "real_bpp", "pred_z_bit", "pred_y_bit", "pred_bit",
            "pred_bpp", "num_pixel"]
@@ -55,7 +55,7 @@ def main():
     p = compress_arg_parser()
     p.add_argument("--batch_size", type=int, default=1)
     p.add_argument("--synthetic_weights", action="store_true")
-    p.add_argument("--io_workers", type=int, default=0, help="PNG decode / encode threads (0: min(8, cores))")
+    p.add_argument("--io_workers", type=int, default=0, help="PNG decode / encode threads (0: min(8, this rank's share of the cores))")
     args = p.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -63,6 +63,7 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
     device = args.device
+    pin_rank_cpus()                      # N ranks share the host: each takes its slice of the cores (rANS + PNG threads)
     if world > 1:
         import torch.distributed as dist_
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -76,6 +77,8 @@ def main():
 
     overrides = {k: v for k, v in vars(args).items() if k not in ("batch_size", "synthetic_weights", "io_workers")}
     overrides["device"] = device
+    if device.startswith("cuda"):
+        torch.cuda.set_device(torch.device(device))      # `-d cuda:1` makes cuda:1 the current device (kernels launch there)
     overrides["is_train"] = False
     opt = BaseConfig.fromfile(args.config_path, overrides)
     ck = opt["subnet"]["vq_model"].get("ckpt_path")

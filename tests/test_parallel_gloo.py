@@ -6,7 +6,7 @@ import numpy as np
 import torch
 import torch.multiprocessing as mp
 
-from dc_vic_amd.parallel import gather_rate_table, shard_indices
+from dc_vic_amd.parallel import gather_rate_table, rank_cpu_slice, shard_indices
 
 
 def test_shard_indices_partition_and_balance():
@@ -22,9 +22,22 @@ def test_shard_indices_partition_and_balance():
 
 
 def _worker(rank, world, port, out_dir):
+    import json
     import torch.distributed as dist
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
+    os.environ["LOCAL_WORLD_SIZE"] = str(world)
+    os.environ["LOCAL_RANK"] = str(rank)
+    os.environ.pop("DCVIC_HOST_THREADS", None)
+    from dc_vic_amd.entropy import host_threads
+    from dc_vic_amd.io_pipeline import default_workers
+    from dc_vic_amd.parallel import host_core_budget, pin_rank_cpus
+    before = sorted(os.sched_getaffinity(0))
+    budget = dict(n_before=len(before), threads_unpinned=host_threads(), io_unpinned=default_workers(), budget_unpinned=host_core_budget())
+    cpus = pin_rank_cpus()
+    budget.update(cpus=cpus, threads_pinned=host_threads(), io_pinned=default_workers())
+    with open(os.path.join(out_dir, f"budget{rank}.json"), "w") as f:
+        json.dump(budget, f)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     n_items = 7
     mine = shard_indices(n_items, rank, world, [10, 1, 1, 1, 9, 1, 1])
@@ -46,3 +59,26 @@ def test_gather_rate_table_world2(tmp_path):
     # single process: identity
     t = np.arange(6, dtype=np.float64).reshape(3, 2)
     assert np.array_equal(gather_rate_table(t, None), t)
+    # host-core budget (the ranks of a node share its cores): each rank takes affinity // LOCAL_WORLD_SIZE
+    # rANS / PNG threads, pinned or not, and the pinned CPU sets of the two ranks are disjoint
+    import json
+    b0, b1 = (json.load(open(tmp_path / f"budget{r}.json")) for r in (0, 1))
+    n = b0["n_before"]
+    share = max(1, n // 2)
+    for b in (b0, b1):
+        assert b["budget_unpinned"] == share
+        assert b["threads_unpinned"] == b["threads_pinned"] == min(16, share)
+        assert b["io_unpinned"] == b["io_pinned"] == min(8, share)
+        assert len(b["cpus"]) == share
+    if n >= 2:
+        assert not set(b0["cpus"]) & set(b1["cpus"])
+    assert b0["threads_pinned"] + b1["threads_pinned"] <= max(n, 2)
+
+
+def test_rank_cpu_slices_cover_and_do_not_overlap():
+    cpus = list(range(3, 3 + 128))
+    for lw in (1, 2, 4, 8):
+        sl = [rank_cpu_slice(r, lw, cpus) for r in range(lw)]
+        flat = [c for s_ in sl for c in s_]
+        assert len(flat) == len(set(flat)) == 128 and all(len(s_) == 128 // lw for s_ in sl)
+    assert rank_cpu_slice(5, 8, [0, 1]) == [1]        # more ranks than cores: wrap, never empty
