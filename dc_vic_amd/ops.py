@@ -286,6 +286,23 @@ def bgemm(A: Tensor, a_strides, B: Tensor, b_strides, out: Tensor, c_strides, ba
     return out
 
 
+def attn_fused(qkv: Tensor, Cc: int, out: Optional[Tensor] = None, force_nw: int = 0) -> Tensor:
+    """Single-head attention over all H*W positions (ldm AttnBlock, model.py:186-196) from a [N, 3C, H, W] map holding
+    q | k | v in its channel thirds -> [N, C, H, W].  Scores stay on chip (online softmax)."""
+    N, C3, H, W = _chk4(qkv, "attn qkv")
+    if C3 != 3 * Cc or not qkv.is_contiguous():
+        raise ValueError("attn_fused needs a contiguous [N, 3C, H, W] q|k|v map")
+    HW = H * W
+    if out is None:
+        out = new(N, Cc, H, W, qkv)
+    _chk4(out, "attn out")
+    base = qkv.data_ptr()
+    check(lib().dcvic_attn_fused_f32(C.c_void_p(base), C.c_void_p(base + 4 * Cc * HW), C.c_void_p(base + 8 * Cc * HW),
+                                     C.c_longlong(3 * Cc * HW), _p(out), C.c_longlong(_bs(out)), N, Cc, HW,
+                                     C.c_float(float(int(Cc) ** (-0.5))), force_nw, _stream()), "attn_fused")
+    return out
+
+
 # ------------------------------------------------------------------------------------------- norms
 def groupnorm(x: Tensor, gamma: Tensor, beta: Tensor, groups: int = 32, eps: float = 1e-6, act: int = ACT_NONE,
               out: Optional[Tensor] = None) -> Tensor:

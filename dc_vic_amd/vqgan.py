@@ -11,6 +11,7 @@ as two fp32-MFMA batched GEMMs around a column softmax.
 """
 from __future__ import annotations
 
+import os
 from typing import Optional, Tuple
 
 import torch
@@ -67,20 +68,32 @@ class AttnBlock(nn.Module):
             self._qkv_key = key
         return self._qkv_plan
 
+    @staticmethod
+    def _attn_unfused(qkv: Tensor, N: int, Cc: int, H: int, W: int) -> Tensor:
+        """Materialised-score form (two batched GEMMs around a column softmax) for token counts the fused kernel does not
+        take (HW not a multiple of 64 never happens on the x64-padded path; kept for direct users of the block)."""
+        HW = H * W
+        bs = 3 * Cc * HW
+        q, k, v = qkv[:, :Cc], qkv[:, Cc:2 * Cc], qkv[:, 2 * Cc:]
+        # scores stored [key j][query i]:  St[j][i] = c^-0.5 * sum_c k[c][j] q[c][i]   (model.py:186-188)
+        St = torch.empty((N, HW, HW), dtype=torch.float32, device=qkv.device)
+        ops.bgemm(k, (bs, 1, HW), q, (bs, HW, 1), St, (HW * HW, HW), N, HW, HW, Cc, alpha=float(int(Cc) ** (-0.5)))
+        ops.softmax_c_(St, N, HW, HW)                  # softmax over keys
+        # h[c][i] = sum_j v[c][j] * P[i][j]                                         (model.py:191-195)
+        ho = torch.empty((N, Cc, H, W), dtype=torch.float32, device=qkv.device)
+        ops.bgemm(v, (bs, HW, 1), St, (HW * HW, HW, 1), ho, (Cc * HW, HW), N, Cc, HW, HW)
+        return ho
+
     def forward(self, x: Tensor, out: Optional[Tensor] = None) -> Tensor:
         N, Cc, H, W = x.shape
         HW = H * W
         h_ = self.norm(x)
         qkv = self._qkv()(h_)                          # [N, 3C, H, W]
-        bs = 3 * Cc * HW
-        q, k, v = qkv[:, :Cc], qkv[:, Cc:2 * Cc], qkv[:, 2 * Cc:]
-        # scores stored [key j][query i]:  St[j][i] = c^-0.5 * sum_c k[c][j] q[c][i]   (model.py:186-188)
-        St = torch.empty((N, HW, HW), dtype=torch.float32, device=x.device)
-        ops.bgemm(k, (bs, 1, HW), q, (bs, HW, 1), St, (HW * HW, HW), N, HW, HW, Cc, alpha=float(int(Cc) ** (-0.5)))
-        ops.softmax_c_(St, N, HW, HW)                  # softmax over keys
-        # h[c][i] = sum_j v[c][j] * P[i][j]                                         (model.py:191-195)
-        ho = torch.empty((N, Cc, H, W), dtype=torch.float32, device=x.device)
-        ops.bgemm(v, (bs, HW, 1), St, (HW * HW, HW, 1), ho, (Cc * HW, HW), N, Cc, HW, HW)
+        if HW % 64 == 0 and Cc in (128, 256, 512) and os.environ.get("DCVIC_ATTN_FUSED", "1") != "0":
+            # flash-style fused kernel: the HW x HW score matrix never reaches HBM (csrc/attn.hip)
+            ho = ops.attn_fused(qkv, Cc)
+        else:
+            ho = self._attn_unfused(qkv, N, Cc, H, W)
         return self.proj_out(ho, res=x, out=out)
 
 

@@ -150,6 +150,14 @@ typedef struct {
 } dcvic_gemm_args;
 int dcvic_bgemm_f32(const dcvic_gemm_args* a, void* stream);
 
+/* Fused single-head attention of the ldm AttnBlock (model.py:186-196: bmm, * c^-0.5, softmax(dim=2), bmm) on NCHW
+ * planes: q, k, v [N][C][HW] (three channel ranges of one tensor are fine: common batch stride in_bs, plane rows
+ * dense), out [N][C][HW].  out[c][i] = sum_j v[c][j] * softmax_j(scale * sum_c q[c][i] k[c][j]).  Online softmax over
+ * 64-key tiles, scores never written to HBM; fp32 MFMA fmaf chains in a fixed order (batch- and grid-invariant).
+ * HW % 64 == 0; C in {128, 256, 512}.  force_nw: 0 = choose, 2 / 4 = waves per workgroup (bit-identical; tests). */
+int dcvic_attn_fused_f32(const float* q, const float* k, const float* v, long long in_bs, float* out, long long out_bs,
+                         int N, int C, int HW, float scale, int force_nw, void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * Normalisation / softmax / elementwise
  */

@@ -189,6 +189,40 @@ def test_attention_gemms(dev, HW, C):
     close(out, ref, rtol=2e-4, atol=2e-5)
 
 
+@pytest.mark.parametrize("N,C,H,W", [(2, 512, 32, 32), (1, 512, 8, 16), (3, 256, 16, 16), (2, 128, 8, 8), (1, 512, 64, 96)])
+def test_attention_fused(dev, N, C, H, W):
+    """Fused single-head attention (csrc/attn.hip) vs the torch fp32 reference of ldm model.py:186-196.  Tolerance:
+    fp32 re-association only (online softmax over 64-key tiles vs one softmax over the row): rtol 2e-4.  The result does
+    not depend on the waves-per-workgroup variant nor on the batch an image travels in (bit-identical)."""
+    from dc_vic_amd import ops
+    HW = H * W
+    q, k, v = 2.0 * rnd(N, C, HW, seed=35), 2.0 * rnd(N, C, HW, seed=36), rnd(N, C, HW, seed=37)
+    w_ = torch.bmm(q.permute(0, 2, 1), k) * (C ** -0.5)
+    w_ = F.softmax(w_, dim=2)
+    ref = torch.bmm(v, w_.permute(0, 2, 1)).view(N, C, H, W)
+    qkv = torch.cat([q, k, v], 1).view(N, 3 * C, H, W).to(dev).contiguous()
+    out = ops.attn_fused(qkv, C)
+    close(out, ref, rtol=2e-4, atol=2e-5)
+    o2, o4 = ops.attn_fused(qkv, C, force_nw=2), ops.attn_fused(qkv, C, force_nw=4)
+    assert torch.equal(o2, o4) and torch.equal(out, o4)
+    one = ops.attn_fused(qkv[N - 1:N].contiguous(), C)
+    assert torch.equal(one[0], out[N - 1])
+    # the materialised-score path (bgemm + softmax + bgemm) agrees to fp32 slack
+    from dc_vic_amd.vqgan import AttnBlock
+    close(AttnBlock._attn_unfused(qkv, N, C, H, W), out, rtol=2e-4, atol=2e-5)
+    with pytest.raises(Exception):
+        ops.attn_fused(torch.zeros(1, 3 * 512, 5, 8, device=dev), 512)          # HW % 64 != 0 -> EINVAL, no launch
+
+
+def test_device_mismatch_raises(dev, monkeypatch):
+    """Kernels launch on the current device's stream: a tensor of another GPU must raise, not launch."""
+    from dc_vic_amd import ops
+    x = torch.zeros(1, 4, 8, 8, device=dev)
+    monkeypatch.setattr(torch.cuda, "current_device", lambda: 1)
+    with pytest.raises(ValueError, match="set_device"):
+        ops.activation(x, ops.ACT_RELU)
+
+
 @pytest.mark.parametrize("H,W,shift", [(16, 16, 0), (16, 16, 4), (8, 24, 4), (32, 32, 4)])
 def test_swin_window_attention(dev, H, W, shift):
     from dc_vic_amd import ops
