@@ -40,6 +40,7 @@ __global__ __launch_bounds__(NW * 64, 1) void attn_fused_kernel(const AttnArgs a
     constexpr int BUF = 64 * KROW;         // words per LDS buffer (the K image is the larger one)
     constexpr int NCC = C / 64;            // chunks per tensor and key tile
     constexpr int NCH = 2 * NCC;           // chunks per key tile (K chunks, then V chunks)
+    constexpr int KD = 3;                  // LDS-read prefetch distance in MFMA steps (4 MFMAs = 128 cycles each)
     extern __shared__ float lds[];         // 2 * BUF
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -75,12 +76,18 @@ __global__ __launch_bounds__(NW * 64, 1) void attn_fused_kernel(const AttnArgs a
         prow[u] = id >> 4;
         pq[u] = id & 15;
     }
+    int poff[PP];
+#pragma unroll
+    for (int u = 0; u < PP; ++u) poff[u] = prow[u] * HW + 4 * pq[u];
     f32x4 st[PP];
     const int nkt = HW / 64;
 
+    // wave-uniform chunk base (SGPRs) + a 32-bit per-lane piece offset: the saddr form of global_load, 1 VGPR per piece
 #define ATTN_ISSUE(T, row0, key0)                                                                             \
-    _Pragma("unroll") for (int u = 0; u < PP; ++u)                                                            \
-        st[u] = *reinterpret_cast<const f32x4*>((T) + (long long)((row0) + prow[u]) * HW + (key0) + 4 * pq[u]);
+    {                                                                                                         \
+        const float* cb_ = (T) + (long long)(row0) * HW + (key0);                                             \
+        _Pragma("unroll") for (int u = 0; u < PP; ++u) st[u] = *reinterpret_cast<const f32x4*>(cb_ + poff[u]); \
+    }
 #define ATTN_STAGE_K(buf)                                                                                     \
     _Pragma("unroll") for (int u = 0; u < PP; ++u) *reinterpret_cast<f32x4*>((buf) + prow[u] * KROW + 4 * pq[u]) = st[u];
     // piece index = key >> 2 = (jt1 jt0 g1 g0); position bits (jt0 g0 jt1 g1 r1 r0)
@@ -92,81 +99,95 @@ __global__ __launch_bounds__(NW * 64, 1) void attn_fused_kernel(const AttnArgs a
         d[0] = st[u][0]; d[1] = st[u][1]; d[2] = st[u][2]; d[3] = st[u][3];                                   \
     }
 
-    // prologue: chunk 0 (K rows 0..63 of key tile 0) -> LDS[0]; chunk 1 in flight
+    const int kbase = g * KROW + il;
+    const int vbase = il * VROW + 16 * (g & 1) + 4 * (g >> 1);
+    // A-operand reads of MFMA step `st_` of a chunk image: K image -> 4 key tiles, V image -> 4 channel tiles
+#define ATTN_READ_K(buf, st_, dst)                                                                            \
+    _Pragma("unroll") for (int x_ = 0; x_ < 4; ++x_) (dst)[x_] = (buf)[kbase + (st_) * 4 * KROW + 16 * x_];
+#define ATTN_READ_V(buf, st_, dst)                                                                            \
+    _Pragma("unroll") for (int x_ = 0; x_ < 4; ++x_)                                                          \
+        (dst)[x_] = (buf)[vbase + x_ * 16 * VROW + 32 * (((st_) >> 2) & 1) + 8 * ((st_) >> 3) + ((st_) & 3)];
+
+    // Two LDS buffers, one barrier per chunk:
+    //   barrier(n) : chunk n is complete in buf[n&1]; every wave has finished reading buf[(n+1)&1] (chunk n-1)
+    //   then       : registers (chunk n+1, requested during chunk n-1) -> buf[(n+1)&1]; request chunk n+2; 64 MFMAs
+    // (a three-buffer ring with the barrier mid-chunk and operand reads running ahead across the chunk seam was built and
+    //  measured slower: it needs ~30 more live registers and hipcc spills inside the loop at the 512-register cap)
     ATTN_ISSUE(K, 0, 0)
     ATTN_STAGE_K(lds)
     if (NCC > 1) { ATTN_ISSUE(K, 64, 0) } else { ATTN_ISSUE(V, 0, 0) }
 
-    const int kbase = g * KROW + il;
-    const int vbase = il * VROW + 16 * (g & 1) + 4 * (g >> 1);
-
     for (int kt = 0; kt < nkt; ++kt) {
-    #pragma unroll
+#pragma unroll
         for (int rem = 0; rem < NCH; ++rem) {
-            float* cur = lds + (rem & 1) * BUF;
-            float* nxt = lds + ((rem + 1) & 1) * BUF;
-            __syncthreads();      // chunk `rem` is in `cur`; every wave is done reading `nxt` (chunk rem - 1)
-            // registers hold chunk rem + 1 -> LDS; then request chunk rem + 2
-            {
-                const int r1 = (rem + 1) % NCH;
+            float* b0 = lds + (rem & 1) * BUF;           // NCH is even: the buffer parity of a chunk is compile-time
+            float* b1 = lds + ((rem + 1) & 1) * BUF;
+            const int r1 = (rem + 1) % NCH;
+            __syncthreads();
+            {   // registers hold chunk rem + 1 -> LDS; then request chunk rem + 2
                 const bool have1 = !(kt == nkt - 1 && rem == NCH - 1);
-                if (have1) { if (r1 < NCC) { ATTN_STAGE_K(nxt) } else { ATTN_STAGE_V(nxt) } }
+                if (have1) { if (r1 < NCC) { ATTN_STAGE_K(b1) } else { ATTN_STAGE_V(b1) } }
                 const int r2 = (rem + 2) % NCH;
                 const int kt2 = kt + ((rem + 2) >= NCH ? 1 : 0);
                 if (kt2 < nkt) {
                     if (r2 < NCC) { ATTN_ISSUE(K, 64 * r2, kt2 * 64) } else { ATTN_ISSUE(V, 64 * (r2 - NCC), kt2 * 64) }
                 }
+                __builtin_amdgcn_sched_barrier(0);    // keep the global loads HERE: a whole chunk of MFMAs covers their latency
             }
-            if (rem < NCC) {
-                if (rem == 0) {
+            if (rem == 0) {
 #pragma unroll
-                    for (int jt = 0; jt < 4; ++jt) S[jt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                for (int jt = 0; jt < 4; ++jt) S[jt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            }
+            // 16 MFMA steps (4 MFMAs each).  Operand reads run KD steps ahead of their MFMAs and sched_barrier pins that
+            // order (left alone, hipcc waits lgkmcnt(0) after each read pair and exposes the LDS latency to every 2nd MFMA)
+            float av[16][4];
+#pragma unroll
+            for (int s = 0; s < KD; ++s) {
+                if (rem < NCC) { ATTN_READ_K(b0, s, av[s]) } else { ATTN_READ_V(b0, s, av[s]) }
+            }
+#pragma unroll
+            for (int s = 0; s < 16; ++s) {
+                const int f = s + KD;
+                if (f < 16) {
+                    if (rem < NCC) { ATTN_READ_K(b0, f, av[f]) } else { ATTN_READ_V(b0, f, av[f]) }
                 }
-                // scores: S^T[key][query] += K[c][key] * q[c][query] over the 64 channels of this chunk
-#pragma unroll
-                for (int s = 0; s < 16; ++s) {
-#pragma unroll
-                    for (int jt = 0; jt < 4; ++jt) {
-                        const float av = cur[kbase + s * 4 * KROW + 16 * jt];
-                        S[jt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, qreg[16 * rem + s], S[jt], 0, 0, 0);
-                    }
-                }
-                if (rem == NCC - 1) {
-                    // online softmax over this tile's 64 keys (16 values per lane, 4 lane groups per query)
-                    float mt = -INFINITY;
+                __builtin_amdgcn_sched_barrier(0);
+                if (rem < NCC) {      // scores: S^T[key][query] += K[c][key] * q[c][query], 4 channels per step
 #pragma unroll
                     for (int jt = 0; jt < 4; ++jt)
+                        S[jt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s][jt], qreg[16 * rem + s], S[jt], 0, 0, 0);
+                } else {              // values: O[c][query] += V[c][key] * P[key][query]; step s = 4 jt + r is key 16 jt + 4 g + r
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) { S[jt][r] *= a.scale; mt = fmaxf(mt, S[jt][r]); }
-                    mt = fmaxf(mt, __shfl_xor(mt, 16, 64));
-                    mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
-                    const float m_new = fmaxf(m_run, mt);
-                    const float alpha = expf(m_run - m_new);
-                    float rs = 0.f;
+                    for (int tt = 0; tt < 4; ++tt)
+                        o[4 * (rem - NCC) + tt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s][tt], S[s >> 2][s & 3], o[4 * (rem - NCC) + tt], 0, 0, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (rem == NCC - 1) {
+                // online softmax over this tile's 64 keys (16 values per lane, 4 lane groups per query)
+                float mt = -INFINITY;
 #pragma unroll
-                    for (int jt = 0; jt < 4; ++jt)
+                for (int jt = 0; jt < 4; ++jt)
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) { const float p = expf(S[jt][r] - m_new); S[jt][r] = p; rs += p; }
-                    rs += __shfl_xor(rs, 16, 64);
-                    rs += __shfl_xor(rs, 32, 64);
-                    l_run = l_run * alpha + rs;
-                    m_run = m_new;
+                    for (int r = 0; r < 4; ++r) { S[jt][r] *= a.scale; mt = fmaxf(mt, S[jt][r]); }
+                mt = fmaxf(mt, __shfl_xor(mt, 16, 64));
+                mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
+                const float m_new = fmaxf(m_run, mt);
+                const float alpha = expf(m_run - m_new);
+                float rs = 0.f;
+#pragma unroll
+                for (int jt = 0; jt < 4; ++jt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) { const float p = expf(S[jt][r] - m_new); S[jt][r] = p; rs += p; }
+                rs += __shfl_xor(rs, 16, 64);
+                rs += __shfl_xor(rs, 32, 64);
+                l_run = l_run * alpha + rs;
+                m_run = m_new;
+                // rescale the output slice only when some query of this wave moved its maximum (x 1.0f is exact, so
+                // skipping it changes no value); after the first tiles that is rare
+                if (__any(alpha != 1.f)) {
 #pragma unroll
                     for (int t = 0; t < C / 16; ++t) o[t] *= alpha;
-                }
-            } else {
-                // values: O[c][query] += V[c][key] * P[key][query] for the 64 channels (4 tiles) of this chunk
-                const int cv = rem - NCC;
-#pragma unroll
-                for (int jt = 0; jt < 4; ++jt) {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-#pragma unroll
-                        for (int tt = 0; tt < 4; ++tt) {
-                            const float av = cur[vbase + tt * 16 * VROW + 32 * (jt & 1) + 8 * (jt >> 1) + r];
-                            o[4 * cv + tt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, S[jt][r], o[4 * cv + tt], 0, 0, 0);
-                        }
-                    }
                 }
             }
         }
@@ -199,11 +220,13 @@ extern "C" int dcvic_attn_fused_f32(const float* q, const float* k, const float*
     DCVIC_CHECK_ARG(((uintptr_t)k % 16) == 0 && ((uintptr_t)v % 16) == 0 && (in_bs % 4) == 0, "attn_fused: k / v planes must be 16-byte aligned");
     AttnArgs A{q, k, v, out, in_bs, out_bs, HW, 0, scale};
     const long long wg4 = (long long)N * (HW / 64);
-    int nw = (wg4 >= dcvic_num_cu()) ? 4 : 2;      // small grids: two waves per workgroup, 2x the workgroups (same values)
-    if (force_nw == 2 || force_nw == 4) nw = force_nw;
+    // small grids: two waves per workgroup, 2x the workgroups (same values); not at C = 512, where the 8-piece staging
+    // registers of a 2-wave workgroup do not fit beside the 272 q / O / S registers (hipcc spills)
+    int nw = (wg4 >= dcvic_num_cu() || C == 512) ? 4 : 2;
+    if ((force_nw == 2 && C != 512) || force_nw == 4) nw = force_nw;
     A.nblocks = (int)(nw == 4 ? wg4 : wg4 * 2);
     hipStream_t st = (hipStream_t)stream;
-    if (C == 512) return nw == 4 ? launch_attn<512, 4>(A, st) : launch_attn<512, 2>(A, st);
+    if (C == 512) return launch_attn<512, 4>(A, st);
     if (C == 256) return nw == 4 ? launch_attn<256, 4>(A, st) : launch_attn<256, 2>(A, st);
     return nw == 4 ? launch_attn<128, 4>(A, st) : launch_attn<128, 2>(A, st);
 }
