@@ -155,9 +155,32 @@ def test_binary_rate_search_script(tmp_path):
     cmd = [sys.executable, os.path.join(ROOT, "scripts", "binary_rate_search.py"), os.path.join(ROOT, "config", "dc_vic_synthetic.yaml"),
            "--save_dir", str(out), "--dataset_root", str(root), "--beta_vq", "3.0", "--target_rate", "0.2", "--max_beta_rate", "3.0",
            "--error_delta", "0.0005", "--batch_size", "2", "--synthetic_weights"]
+    cmd[cmd.index("--beta_vq") + 1:cmd.index("--beta_vq") + 2] = ["3.0", "2.0"]
     subprocess.check_call(cmd, cwd=ROOT)
     import pandas as pd
     df = pd.read_csv(out / "result_beta_vq_3.00_target_rate_0.200.csv", index_col=0)
     assert list(df.columns) == ["run_cnt", "beta_vq", "beta_rate", "avg_bpp", "diff"]
     assert 1 <= len(df) <= 10 and (df["diff"].values[:-1] <= df["diff"].values[1:]).all()      # sorted by diff
     assert (df["avg_bpp"] > 0).all() and (df["beta_rate"] >= 0).all() and (df["beta_rate"] <= 3.0).all()
+    # beta_selection.py on top of the search results (reference scripts/beta_selection.py:158-246): reconstructions via
+    # run_model at the selected beta_rate, bpp within the search tolerance of the target, PSNR from the written PNGs
+    sel = tmp_path / "selection"
+    cmd = [sys.executable, os.path.join(ROOT, "scripts", "beta_selection.py"), os.path.join(ROOT, "config", "dc_vic_synthetic.yaml"),
+           "--search_dir", str(out), "--save_dir", str(sel), "--dataset_root", str(root), "--beta_vq", "3.0", "2.0", "--target_rate", "0.2",
+           "--batch_size", "2", "--keep_recon", "--synthetic_weights"]
+    subprocess.check_call(cmd, cwd=ROOT)
+    res = pd.read_csv(sel / "target_rate_0.2" / "result.csv", index_col=0)
+    assert list(res.columns) == ["beta_vq", "beta_rate", "bpp", "psnr", "fid", "score"]
+    ok = [bv for bv in (3.0, 2.0) if pd.read_csv(out / f"result_beta_vq_{bv:.2f}_target_rate_0.200.csv").sort_values("diff").iloc[0]["diff"] <= 1e-3]
+    assert sorted(res["beta_vq"]) == sorted(ok) and len(ok) >= 1
+    for _, r in res.iterrows():
+        best = pd.read_csv(out / f"result_beta_vq_{r['beta_vq']:.2f}_target_rate_0.200.csv").sort_values("diff").iloc[0]
+        assert abs(r["bpp"] - best["avg_bpp"]) < 1e-6          # run_model's rate == the search probe's rate (same kernels)
+        assert np.isfinite(r["psnr"]) and 5.0 < r["psnr"] < 60.0 and abs(r["score"] - 2.0 * r["psnr"]) < 1e-9
+        rd = sel / "target_rate_0.2" / f"beta_vq_{r['beta_vq']:.2f}"
+        assert sorted(os.listdir(rd)) == ["0.png", "1.png", "2.png", "_avg_bitrate.json", "_rate_summary.csv"]
+        rs = pd.read_csv(rd / "_rate_summary.csv", index_col=0)
+        assert list(rs.columns) == ["img_name", "num_pixel", "total_bit", "bitrate"] and (rs["num_pixel"] == 128 * 128).all()
+    top = pd.read_csv(sel / "beta_selection_results.csv")
+    assert list(top.columns) == ["target_rate", "selected_beta_vq", "selected_beta_rate"] and len(top) == 1
+    assert top.iloc[0]["selected_beta_vq"] == res.iloc[0]["beta_vq"]
