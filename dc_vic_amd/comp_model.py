@@ -342,7 +342,8 @@ class HyperpriorVicModel(BaseModel):
             return zq, idx
         N, _, H, W = real_images.shape
         _z = self._vq_encode_split(real_images) if max(H, W) > SPLIT_DECODE_RESOLUTION else self.vq_model.encode(real_images)
-        assert not (max(H, W) > 1024 and self.n_embed > 1024), "_vq_quantize_split is only needed for n_embed > 1024"
+        # n_embed > 1024 (hyperprior_vic_model.py:149-150 `_vq_quantize_split`, which chunks the latent to bound the [HW, n_e]
+        # distance matrix): the sharded-codebook kernel streams the codebook through LDS instead, any size in one launch
         r = self.vq_model.quantize(_z, want_feat=want_feat)
         if want_feat:
             zq, _, (_, _, idx), feat = r

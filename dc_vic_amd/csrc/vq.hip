@@ -186,15 +186,126 @@ __global__ __launch_bounds__(256) void vq_argmin4_kernel(const float* __restrict
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Sharded-codebook search on the matrix cores (D == 4, n_e a multiple of 256, ANY codebook size -- 16 384 x 4 and beyond,
+// which do not fit one LDS image; reference: hyperprior_vic_model.py:149-150,170-188 `_vq_quantize_split`).
+//   * the codebook streams through LDS in SHARDS of 256 codes ([dim][code] image + squared norms, 5.3 KiB);
+//   * the dot products are v_mfma_f32_16x16x4_f32 with K = 4 = the code dimension: A = 16 codes x 4 dims, B = 4 dims x 16
+//     latent vectors, C = 0.  The instruction is an exact k-ordered fmaf chain (tools/mfma_order.hip), i.e. bit for bit
+//     the generic kernel's  fma(z3,e3, fma(z2,e2, fma(z1,e1, z0*e0)));
+//   * lane (vector v = lane % 16, group g = lane / 16) then owns the distances of ITS vector to codes 16 t + 4 g + r of every
+//     tile t: d = fma(-2, dot, |z|^2 + |e|^2) (the reference's expanded form, same roundings as the kernels above), a running
+//     (best, index) per lane with a strict `<` in ascending code order;
+//   * the four lane groups of a vector are merged by a WAVEFRONT SHUFFLE (d, idx) reduction (xor 16, xor 32): smaller
+//     distance wins, equal distances -> smaller index, so the result is torch.argmin's first minimum.
+// A wave owns VT = 4 vector tiles (64 latent vectors), a workgroup 256 vectors; z is read once, coalesced along pixels.
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+#define VQS 256                     // codes per shard
+#define VQS_ROW (VQS + 16)          // [dim][code] row stride: lane groups g, g+1 land 16 banks apart (conflict-free)
+
+__global__ __launch_bounds__(256) void vq_shard_mfma_kernel(const float* __restrict__ z, const float* __restrict__ cb,
+                                                            int64_t* __restrict__ idx, float* __restrict__ zq,
+                                                            float* __restrict__ feat, int HW, int n_e) {
+    constexpr int VT = 4;
+    __shared__ __attribute__((aligned(16))) float Es[4 * VQS_ROW];
+    __shared__ __attribute__((aligned(16))) float E2s[VQS];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int vl = lane & 15, g = lane >> 4;
+    const int n = blockIdx.y;
+    const int pbase = blockIdx.x * 256 + wave * 64;
+    const float* zn = z + (long long)n * 4 * HW;
+    float zg[VT], z2[VT], zall[VT][4], best[VT];
+    int bi[VT];
+#pragma unroll
+    for (int vt = 0; vt < VT; ++vt) {
+        const int p = min(pbase + vt * 16 + vl, HW - 1);
+        zg[vt] = zn[(long long)g * HW + p];                          // B operand: z[dim g][vector vl]
+#pragma unroll
+        for (int d = 0; d < 4; ++d) zall[vt][d] = __shfl(zg[vt], vl + 16 * d, 64);
+        float s2 = __fmul_rn(zall[vt][0], zall[vt][0]);
+#pragma unroll
+        for (int d = 1; d < 4; ++d) s2 = __fadd_rn(s2, __fmul_rn(zall[vt][d], zall[vt][d]));
+        z2[vt] = s2; best[vt] = INFINITY; bi[vt] = 0;
+    }
+    for (int s0 = 0; s0 < n_e; s0 += VQS) {
+        __syncthreads();                                             // the previous shard has been consumed
+        {   // stage shard [s0, s0 + 256): thread tid owns code s0 + tid (one float4), transposed into the [dim][code] image
+            const f32x4v e = *reinterpret_cast<const f32x4v*>(cb + (long long)(s0 + tid) * 4);
+            Es[0 * VQS_ROW + tid] = e[0]; Es[1 * VQS_ROW + tid] = e[1]; Es[2 * VQS_ROW + tid] = e[2]; Es[3 * VQS_ROW + tid] = e[3];
+            float sq = __fmul_rn(e[0], e[0]);
+            sq = __fadd_rn(sq, __fmul_rn(e[1], e[1])); sq = __fadd_rn(sq, __fmul_rn(e[2], e[2])); sq = __fadd_rn(sq, __fmul_rn(e[3], e[3]));
+            E2s[tid] = sq;
+        }
+        __syncthreads();
+        float ea[16];                                                // A operands of the 16 code tiles: E[16 t + vl][dim g]
+#pragma unroll
+        for (int t = 0; t < 16; ++t) ea[t] = Es[g * VQS_ROW + 16 * t + vl];
+#pragma unroll
+        for (int vt = 0; vt < VT; ++vt) {
+#pragma unroll
+            for (int t = 0; t < 16; ++t) {
+                const f32x4v dot = __builtin_amdgcn_mfma_f32_16x16x4f32(ea[t], zg[vt], (f32x4v){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+                const f32x4v e2 = *reinterpret_cast<const f32x4v*>(&E2s[16 * t + 4 * g]);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {                        // code s0 + 16 t + 4 g + r, ascending inside the lane
+                    const float dist = fmaf(-2.f, dot[r], __fadd_rn(z2[vt], e2[r]));
+                    const bool lt = dist < best[vt];
+                    best[vt] = lt ? dist : best[vt];
+                    bi[vt] = lt ? (s0 + 16 * t + 4 * g + r) : bi[vt];
+                }
+            }
+        }
+    }
+    // wavefront (d, idx) reduction over the four lane groups of each vector
+#pragma unroll
+    for (int vt = 0; vt < VT; ++vt) {
+#pragma unroll
+        for (int o = 16; o <= 32; o <<= 1) {
+            const float od = __shfl_xor(best[vt], o, 64);
+            const int oi = __shfl_xor(bi[vt], o, 64);
+            const bool take = (od < best[vt]) || (od == best[vt] && oi < bi[vt]);
+            best[vt] = take ? od : best[vt];
+            bi[vt] = take ? oi : bi[vt];
+        }
+        const int p = pbase + vt * 16 + vl;
+        if (g != 0 || p >= HW) continue;
+        const int b = bi[vt];
+        idx[(long long)n * HW + p] = (int64_t)b;
+        float q[4];
+#pragma unroll
+        for (int d = 0; d < 4; ++d) q[d] = __fadd_rn(zall[vt][d], __fsub_rn(cb[(long long)b * 4 + d], zall[vt][d]));
+        if (zq) {
+#pragma unroll
+            for (int d = 0; d < 4; ++d) zq[(long long)n * 4 * HW + (long long)d * HW + p] = q[d];
+        }
+        if (feat) {
+            float* fp = feat + (long long)n * (4 + n_e) * HW + p;
+#pragma unroll
+            for (int d = 0; d < 4; ++d) fp[(long long)d * HW] = q[d];
+            for (int j = 0; j < n_e; ++j) fp[(long long)(4 + j) * HW] = (j == b) ? 1.0f : 0.0f;
+        }
+    }
+}
+
 extern "C" int dcvic_vq_argmin_f32(const float* z, const float* codebook, int64_t* idx, float* zq, float* feat, int N, int D,
                                    int HW, int n_e, void* stream) {
     DCVIC_CHECK_ARG(z && codebook && idx && N > 0 && HW > 0 && n_e > 0, "vq_argmin: bad argument");
     DCVIC_CHECK_ARG(D == 4 || D == 8, "vq_argmin: embed_dim %d unsupported (4 or 8)", D);
-    DCVIC_CHECK_ARG((size_t)n_e * (D + 1) * 4 <= 160 * 1024, "vq_argmin: codebook %d x %d does not fit LDS", n_e, D);
     DCVIC_CHECK_ARG(N <= 65535, "vq_argmin: batch too large");
+    // DCVIC_VQ_KERNEL = shard | scalar | lds forces a variant (measurements, tests); every variant returns the same indices
+    const char* force = getenv("DCVIC_VQ_KERNEL");
+    const bool fits_lds = (size_t)n_e * (D + 1) * 4 <= 160 * 1024;
+    const bool shard_ok = D == 4 && n_e % VQS == 0 && ((uintptr_t)codebook % 16) == 0;
+    if (shard_ok && (n_e > 1024 || (force && force[0] == 's' && force[1] == 'h'))) {
+        dim3 grids(dcvic_cdiv(HW, 256), N);
+        vq_shard_mfma_kernel<<<grids, 256, 0, (hipStream_t)stream>>>(z, codebook, idx, zq, feat, HW, n_e);
+        DCVIC_CHECK_LAUNCH("vq_argmin(shard)");
+        return DCVIC_OK;
+    }
+    DCVIC_CHECK_ARG(fits_lds, "vq_argmin: codebook %d x %d fits neither one LDS image nor the sharded kernel (D = 4, n_e %% 256 == 0)", n_e, D);
     dim3 grid(dcvic_cdiv(HW, 256), N);
     const size_t lds = (size_t)n_e * (D + 1) * sizeof(float);
-    if (D == 4 && n_e % 8 == 0) {
+    if (D == 4 && n_e % 8 == 0 && n_e <= 1024 && !(force && force[0] == 'l')) {
         // big launches: 4 vectors per lane (1024-vector tiles); small ones keep 512-vector tiles so the chip still fills
         const bool big = (long long)N * dcvic_cdiv(HW, 1024) >= 2048;
         if (big) {
@@ -205,12 +316,12 @@ extern "C" int dcvic_vq_argmin_f32(const float* z, const float* codebook, int64_
             vq_argmin4_kernel<1><<<grid4, 256, (size_t)n_e * sizeof(float), (hipStream_t)stream>>>(z, codebook, idx, zq, feat, HW, n_e);
         }
     } else if (D == 4) {
-        static bool set4g = false;
-        if (!set4g) { hipFuncSetAttribute(reinterpret_cast<const void*>(vq_argmin_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); set4g = true; }
+        static std::atomic<unsigned> m4{0};
+        if (dcvic_first_use_on_device(m4)) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(vq_argmin_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         vq_argmin_kernel<4><<<grid, 256, lds, (hipStream_t)stream>>>(z, codebook, idx, zq, feat, HW, n_e);
     } else {
-        static bool set8 = false;
-        if (!set8) { hipFuncSetAttribute(reinterpret_cast<const void*>(vq_argmin_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); set8 = true; }
+        static std::atomic<unsigned> m8{0};
+        if (dcvic_first_use_on_device(m8)) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(vq_argmin_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         vq_argmin_kernel<8><<<grid, 256, lds, (hipStream_t)stream>>>(z, codebook, idx, zq, feat, HW, n_e);
     }
     DCVIC_CHECK_LAUNCH("vq_argmin");

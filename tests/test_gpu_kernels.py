@@ -214,6 +214,46 @@ def test_attention_fused(dev, N, C, H, W):
         ops.attn_fused(torch.zeros(1, 3 * 512, 5, 8, device=dev), 512)          # HW % 64 != 0 -> EINVAL, no launch
 
 
+@pytest.mark.parametrize("n_e", [256, 1024, 16384])
+def test_vq_sharded_codebook_mfma(dev, n_e, monkeypatch):
+    """Sharded-codebook search (256-code shards through LDS, fp32 MFMA 16x16x4 dots with K = the code dimension, wavefront
+    shuffle (d, idx) reduction): indices identical to the one-LDS-image kernel where that one applies, and -- at
+    16 384 x 4, which fits no LDS image -- index-exact vs the oracle's VectorQuantizer2 restatement (quantize.py:271-312)
+    up to expanded-form fp32 near-ties, itemised.  Includes a ragged pixel count and exact duplicate codes (first wins)."""
+    from dc_vic_amd import ops
+    from oracle import dcvic_oracle as O
+    g = torch.Generator().manual_seed(60 + n_e % 7)
+    cb = (torch.rand((n_e, 4), generator=g) * 2 - 1) / n_e
+    cb[n_e // 2 + 3] = cb[5]                       # duplicate code: the first (index 5) must win every tie
+    z = torch.randn((2, 4, 23, 41), generator=g) * (0.6 / n_e)
+    z[0, :, 0, 0] = cb[5]                          # exact hit on the duplicated code
+    zd, cbd = z.to(dev).contiguous(), cb.to(dev).contiguous()
+    monkeypatch.setenv("DCVIC_VQ_KERNEL", "shard")
+    idx_s, zq_s, _ = ops.vq_argmin(zd, cbd, want_zq=True)
+    monkeypatch.delenv("DCVIC_VQ_KERNEL")
+    assert int(idx_s[0, 0, 0]) == 5
+    zq_o, idx_o = O.vq_quantize({"vq_model.quantize.embedding.weight": cb}, z)
+    mism = (idx_s.cpu() != idx_o).nonzero()
+    zf = z.permute(0, 2, 3, 1).double()
+    for nn, y, x in mism.tolist():                 # a disagreement must be a near-tie of the expanded-form distance
+        a, b = int(idx_s[nn, y, x]), int(idx_o[nn, y, x])
+        da, db = ((zf[nn, y, x] - cb[a].double()) ** 2).sum(), ((zf[nn, y, x] - cb[b].double()) ** 2).sum()
+        assert abs(float(da - db)) <= 4e-7 * float((zf[nn, y, x] ** 2).sum() + (cb[b].double() ** 2).sum()), (a, b, float(da - db))
+    assert len(mism) <= 2
+    ok = (idx_s.cpu() == idx_o)
+    assert torch.equal(zq_s.cpu().permute(0, 2, 3, 1)[ok], zq_o.permute(0, 2, 3, 1)[ok])
+    if n_e <= 1024:                                # same roundings as the other kernels: identical indices, always
+        monkeypatch.setenv("DCVIC_VQ_KERNEL", "lds")
+        idx_l, _, _ = ops.vq_argmin(zd, cbd, want_zq=False)
+        monkeypatch.delenv("DCVIC_VQ_KERNEL")
+        idx_d, _, _ = ops.vq_argmin(zd, cbd, want_zq=False)        # default (scalar-cache packed-fp32 kernel)
+        assert torch.equal(idx_s, idx_l) and torch.equal(idx_s, idx_d)
+        _, _, feat = ops.vq_argmin(zd, cbd, want_zq=False, want_feat=True)
+        monkeypatch.setenv("DCVIC_VQ_KERNEL", "shard")
+        _, _, feat_s = ops.vq_argmin(zd, cbd, want_zq=False, want_feat=True)
+        assert torch.equal(feat, feat_s)
+
+
 def test_device_mismatch_raises(dev, monkeypatch):
     """Kernels launch on the current device's stream: a tensor of another GPU must raise, not launch."""
     from dc_vic_amd import ops
