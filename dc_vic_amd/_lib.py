@@ -62,6 +62,11 @@ SYMBOLS = [
     "dcvic_pmf_to_quantized_cdf_host", "dcvic_tables_create_host", "dcvic_tables_destroy_host",
     "dcvic_rans_encode_batch_host", "dcvic_rans_decoder_create_host", "dcvic_rans_decoder_destroy_host",
     "dcvic_rans_decode_batch_host",
+    # training step (csrc/train.hip)
+    "dcvic_conv_wgrad_workspace_floats", "dcvic_conv_wgrad_f32", "dcvic_chan_reduce_f32", "dcvic_sum_rows_f32", "dcvic_ew_bwd_f32",
+    "dcvic_groupnorm_bwd_f32", "dcvic_layernorm_c_bwd_blocks", "dcvic_layernorm_c_bwd_f32", "dcvic_softmax_c_bwd_f32",
+    "dcvic_swin_attn_bwd_f32", "dcvic_reduce_loss_f32", "dcvic_cross_entropy_f32", "dcvic_adam_step_f32", "dcvic_clip_scale_f32",
+    "dcvic_resample2_f32",
 ]
 
 _lib = None
@@ -83,6 +88,7 @@ def lib() -> C.CDLL:
     L = C.CDLL(LIB_PATH)
     L.dcvic_last_error.restype = C.c_char_p
     L.dcvic_conv_packed_bytes.restype = C.c_size_t
+    L.dcvic_conv_wgrad_workspace_floats.restype = C.c_longlong
     L.dcvic_tables_create_host.restype = C.c_void_p
     L.dcvic_rans_decoder_create_host.restype = C.c_void_p
     L.dcvic_tables_destroy_host.argtypes = [C.c_void_p]

@@ -224,9 +224,11 @@ __global__ __launch_bounds__(NTHREADS, (MT * NT >= 8) ? 2 : ((MT * NT >= 4) ? 3 
 
 // ------------------------------------------------------------------------------------------------
 // weight packing: [cotile][chunk][tap][k][TC]
+struct PackTaps { int8_t ky[DCVIC_MAX_TAPS], kx[DCVIC_MAX_TAPS]; };   // travels as a kernel argument: no allocation, no sync
+
 __global__ void conv_pack_kernel(const float* __restrict__ w, float* __restrict__ wp, int Cin, int Cout, int T,
                                  int KH, int KW, int transposed, int TC, int n_chunks, long long total,
-                                 const int* __restrict__ tapk) {
+                                 const PackTaps tapk) {
     long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= total) return;
     long long r = i;
@@ -238,7 +240,7 @@ __global__ void conv_pack_kernel(const float* __restrict__ w, float* __restrict_
     const int co = cotile * TC + col, ci = chunk * KC + k;
     float v = 0.f;
     if (co < Cout && ci < Cin) {
-        const int ky = tapk[2 * t], kx = tapk[2 * t + 1];
+        const int ky = tapk.ky[t], kx = tapk.kx[t];
         const long long idx = transposed ? (((long long)ci * Cout + co) * KH + ky) * KW + kx
                                          : (((long long)co * Cin + ci) * KH + ky) * KW + kx;
         v = w[idx];
@@ -358,17 +360,11 @@ extern "C" int dcvic_conv_pack_f32(const dcvic_conv_desc* d, const float* w, flo
     DCVIC_CHECK_ARG(d->cfg >= 0 && d->cfg <= 3, "conv_pack: bad cfg %d", d->cfg);
     const int TC = cfg_TC(d->cfg);
     const long long total = (long long)n_cotiles_of(d) * n_chunks_of(d) * d->T * KC * TC;
-    // the tap->kernel index table travels through a tiny device buffer; pack is a load-time operation
-    int h_tapk[2 * DCVIC_MAX_TAPS];
-    for (int t = 0; t < d->T; ++t) { h_tapk[2 * t] = d->tap_ky[t]; h_tapk[2 * t + 1] = d->tap_kx[t]; }
-    int* d_tapk = nullptr;
-    if (hipMalloc(&d_tapk, sizeof(h_tapk)) != hipSuccess) { dcvic_set_error("conv_pack: hipMalloc"); return DCVIC_ELAUNCH; }
-    hipMemcpyAsync(d_tapk, h_tapk, sizeof(int) * 2 * d->T, hipMemcpyHostToDevice, (hipStream_t)stream);
+    PackTaps taps;
+    for (int t = 0; t < DCVIC_MAX_TAPS; ++t) { taps.ky[t] = t < d->T ? d->tap_ky[t] : 0; taps.kx[t] = t < d->T ? d->tap_kx[t] : 0; }
     conv_pack_kernel<<<dcvic_cdiv(total, 256), 256, 0, (hipStream_t)stream>>>(w, packed, d->Cin, d->Cout, d->T, d->KH, d->KW,
-                                                                        d->transposed_weight, TC, n_chunks_of(d), total, d_tapk);
+                                                                        d->transposed_weight, TC, n_chunks_of(d), total, taps);
     hipError_t e = hipGetLastError();
-    hipStreamSynchronize((hipStream_t)stream);
-    hipFree(d_tapk);
     if (e != hipSuccess) { dcvic_set_error("conv_pack: %s", hipGetErrorString(e)); return DCVIC_ELAUNCH; }
     return DCVIC_OK;
 }

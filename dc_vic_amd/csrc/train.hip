@@ -1,0 +1,638 @@
+// train.hip -- backward / loss / optimizer kernels of the training step (reference:
+// src/trainer/dual_cond_gan_distortion_vq_code_trainer.py:135-300, src/losses/*, torch autograd of the layers in a14-a17).
+// Forward kernels are the inference ones; data-gradients of convolutions reuse them too (the adjoint of a convolution is a
+// convolution with transposed / flipped weights, of a stride-2 transposed convolution a stride-2 convolution).  New here:
+//   conv_wgrad      dW = sum_pixels dY (x) X   -- fp32 MFMA, split over pixel slabs, slab partials reduced in a FIXED order
+//   groupnorm / layernorm backward (+ fused swish), activation and gate backwards, per-channel reductions,
+//   column-softmax backward (attention), Swin window-attention backward, MSE / BCE-with-logits / cross-entropy with
+//   gradients, Adam, deterministic sum of squares (gradient clipping).
+// Everything is deterministic: no atomics, reductions in a layer-defined order (DDP ranks and reruns agree bit for bit).
+#include "common.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+__device__ __forceinline__ double wsum_d(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wsum_f(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+// block-wide fp64 sum, fixed order (waves ascending); red: >= 16 doubles
+__device__ __forceinline__ double bsum_d(double v, double* red) {
+    v = wsum_d(v);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    __syncthreads();
+    if (lane == 0) red[w] = v;
+    __syncthreads();
+    double t = 0.0;
+    for (int i = 0; i < nw; ++i) t += red[i];
+    return t;
+}
+
+// ------------------------------------------------------------------------------------------------ conv weight gradient
+// dW[m][c][ky][kx] = sum_{n, oy, ox} G[n][m][oy][ox] * X[n][c][oy*s + ky - pt][ox*s + kx - pl]
+// (Conv2d: G = dY, X = the layer input, dW in the Conv2d layout [Cout][Cin][KH][KW].  ConvTranspose2d(stride s): G = the
+//  layer INPUT, X = dY, and the result is the ConvTranspose2d layout [Cin][Cout][KH][KW].)
+// GEMM view per kernel row ky: M = 128 rows m, N = 32 columns c (x KW taps), K = pixels.  A = G[m][pix], B = X[c][pix+tap]:
+// both operands have the contraction index contiguous in memory, so the LDS images are [row][pix] with ODD row strides and
+// the MFMA 32x32x2 operand reads (lane -> row, lane half -> pixel parity) are conflict-free.
+// Workgroup = (m block of 128, c block of 32, ky, pixel slab); 4 waves, wave w owns rows 32 w .. 32 w + 31 and KW accumulators.
+// Partials [slab][m][c][ky][kx] are reduced by wgrad_reduce_kernel in ascending slab order.
+struct WgradArgs {
+    const float* G; long long g_bs; int M, Hg, Wg;       // "gradient-side" map: N x M x Hg x Wg (pixel index of the sum)
+    const float* X; long long x_bs; int Cx, Hx, Wx;      // "input-side" map:    N x Cx x Hx x Wx
+    float* part;                                         // [slabs][M][Cx][KH][KW]
+    int N, KH, KW, stride, pt, pl;
+    int rows_per_slab, slabs_per_img;
+    int mblocks, cblocks;
+};
+
+template <int KWT>
+__global__ __launch_bounds__(256, 1) void conv_wgrad_kernel(const WgradArgs a) {
+    constexpr int PX = 32;                 // pixels per chunk (16 MFMA k-steps)
+    constexpr int AS = 33;                 // A image row stride
+    extern __shared__ float sm[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lr = lane & 31, lh = lane >> 5;
+    int b = blockIdx.x;
+    const int mb = b % a.mblocks; b /= a.mblocks;
+    const int cb = b % a.cblocks; b /= a.cblocks;
+    const int ky = b % a.KH; b /= a.KH;
+    const int slab = b;
+    const int n = slab / a.slabs_per_img, srow0 = (slab % a.slabs_per_img) * a.rows_per_slab;
+    const int xw = (PX - 1) * a.stride + a.KW;             // input pixels per chunk row
+    const int XS = xw | 1;                                  // odd
+    float* As = sm;                                        // [128][AS]
+    float* Xs = sm + 128 * AS;                             // [32][XS]
+    f32x16 acc[KWT];
+#pragma unroll
+    for (int t = 0; t < KWT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+    const float* Gn = a.G + (long long)n * a.g_bs;
+    const float* Xn = a.X + (long long)n * a.x_bs;
+    const int m0 = mb * 128, c0 = cb * 32;
+    const int rend = min(srow0 + a.rows_per_slab, a.Hg);
+    for (int oy = srow0; oy < rend; ++oy) {
+        const int iy = oy * a.stride + ky - a.pt;
+        const bool rowok = iy >= 0 && iy < a.Hx;
+        for (int ox0 = 0; ox0 < a.Wg; ox0 += PX) {
+            __syncthreads();
+            for (int e = tid; e < 128 * PX; e += 256) {            // A: G[m0 + r][oy][ox0 + p]
+                const int r = e >> 5, p = e & 31;
+                float v = 0.f;
+                if (m0 + r < a.M && ox0 + p < a.Wg) v = Gn[((long long)(m0 + r) * a.Hg + oy) * a.Wg + ox0 + p];
+                As[r * AS + p] = v;
+            }
+            const int ix0 = ox0 * a.stride - a.pl;
+            for (int e = tid; e < 32 * xw; e += 256) {             // B: X[c0 + c][iy][ix0 + q]
+                const int c = e / xw, q = e - c * xw;
+                const int ix = ix0 + q;
+                float v = 0.f;
+                if (rowok && c0 + c < a.Cx && ix >= 0 && ix < a.Wx) v = Xn[((long long)(c0 + c) * a.Hx + iy) * a.Wx + ix];
+                Xs[c * XS + q] = v;
+            }
+            __syncthreads();
+            const float* ap = As + (wave * 32 + lr) * AS + lh;
+            const float* xp = Xs + lr * XS + lh * a.stride;
+#pragma unroll 4
+            for (int s = 0; s < PX / 2; ++s) {
+                const float av = ap[2 * s];
+#pragma unroll
+                for (int t = 0; t < KWT; ++t) {
+                    const float bv = xp[2 * s * a.stride + t];
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[t], 0, 0, 0);
+                }
+            }
+        }
+    }
+    // partial[slab][m][c][ky][kx]; accumulator: col = lane%32 -> c, row = (r&3) + 8 (r>>2) + 4 (lane>>5) -> m
+    float* P = a.part + (long long)slab * a.M * a.Cx * a.KH * a.KW;
+    const int c = c0 + lr;
+    if (c < a.Cx) {
+#pragma unroll
+        for (int t = 0; t < KWT; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                if (m < a.M && t < a.KW) P[(((long long)m * a.Cx + c) * a.KH + ky) * a.KW + t] = acc[t][r];
+            }
+    }
+}
+
+// out[i] (+)= sum_s part[s][i], s ascending
+__global__ void slab_reduce_kernel(const float* __restrict__ part, float* __restrict__ out, long long len, int slabs, int accumulate) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= len) return;
+    float s = accumulate ? out[i] : 0.f;
+    for (int k = 0; k < slabs; ++k) s += part[(long long)k * len + i];
+    out[i] = s;
+}
+
+extern "C" long long dcvic_conv_wgrad_workspace_floats(int N, int M, int Cx, int KH, int KW, int Hg, int* slabs_out) {
+    // slabs: whole images split into row groups so that the launch has >= ~512 workgroups
+    const int mblocks = dcvic_cdiv(M, 128), cblocks = dcvic_cdiv(Cx, 32);
+    const long long base = (long long)mblocks * cblocks * KH * N;
+    int per_img = 1;
+    while (base * per_img < 512 && per_img < Hg) per_img *= 2;
+    per_img = per_img > Hg ? Hg : per_img;
+    const int rows = dcvic_cdiv(Hg, per_img);
+    per_img = dcvic_cdiv(Hg, rows);
+    if (slabs_out) *slabs_out = N * per_img;
+    return (long long)N * per_img * M * Cx * KH * KW;
+}
+
+extern "C" int dcvic_conv_wgrad_f32(const float* G, long long g_bs, int M, int Hg, int Wg, const float* X, long long x_bs, int Cx, int Hx,
+                                    int Wx, int N, int KH, int KW, int stride, int pt, int pl, float* dW, int accumulate, float* workspace,
+                                    void* stream) {
+    DCVIC_CHECK_ARG(G && X && dW && workspace, "conv_wgrad: null pointer");
+    DCVIC_CHECK_ARG(KW >= 1 && KW <= 5 && KH >= 1 && KH <= 5 && stride >= 1 && stride <= 4, "conv_wgrad: kernel %dx%d stride %d unsupported", KH, KW, stride);
+    int slabs = 0;
+    dcvic_conv_wgrad_workspace_floats(N, M, Cx, KH, KW, Hg, &slabs);
+    WgradArgs a;
+    a.G = G; a.g_bs = g_bs; a.M = M; a.Hg = Hg; a.Wg = Wg;
+    a.X = X; a.x_bs = x_bs; a.Cx = Cx; a.Hx = Hx; a.Wx = Wx;
+    a.part = workspace; a.N = N; a.KH = KH; a.KW = KW; a.stride = stride; a.pt = pt; a.pl = pl;
+    a.slabs_per_img = slabs / N; a.rows_per_slab = dcvic_cdiv(Hg, a.slabs_per_img);
+    a.mblocks = dcvic_cdiv(M, 128); a.cblocks = dcvic_cdiv(Cx, 32);
+    const long long blocks = (long long)a.mblocks * a.cblocks * KH * slabs;
+    DCVIC_CHECK_ARG(blocks < (1ll << 31), "conv_wgrad: grid too large");
+    const int xw = 31 * stride + KW;
+    const size_t lds = (size_t)(128 * 33 + 32 * (xw | 1)) * sizeof(float);
+    hipStream_t st = (hipStream_t)stream;
+    switch (KW) {
+        case 1: conv_wgrad_kernel<1><<<(unsigned)blocks, 256, lds, st>>>(a); break;
+        case 2: conv_wgrad_kernel<2><<<(unsigned)blocks, 256, lds, st>>>(a); break;
+        case 3: conv_wgrad_kernel<3><<<(unsigned)blocks, 256, lds, st>>>(a); break;
+        case 4: conv_wgrad_kernel<4><<<(unsigned)blocks, 256, lds, st>>>(a); break;
+        default: conv_wgrad_kernel<5><<<(unsigned)blocks, 256, lds, st>>>(a); break;
+    }
+    DCVIC_CHECK_LAUNCH("conv_wgrad");
+    const long long len = (long long)M * Cx * KH * KW;
+    slab_reduce_kernel<<<dcvic_cdiv(len, 256), 256, 0, st>>>(workspace, dW, len, slabs, accumulate);
+    DCVIC_CHECK_LAUNCH("conv_wgrad_reduce");
+    return DCVIC_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ per-channel reductions
+// out[n][c] = sum_p a[n][c][p] * (b ? b[n][c][p] : 1)   (bias gradients, beta-FT scale / shift gradients); fp64 inside
+__global__ __launch_bounds__(256) void chan_reduce_kernel(const float* __restrict__ a, long long a_bs, const float* __restrict__ b,
+                                                          long long b_bs, float* __restrict__ out, int C, int HW) {
+    __shared__ double red[16];
+    const int n = blockIdx.x / C, c = blockIdx.x % C;
+    const float* ap = a + (long long)n * a_bs + (long long)c * HW;
+    const float* bp = b ? b + (long long)n * b_bs + (long long)c * HW : nullptr;
+    double s = 0.0;
+    for (int i = threadIdx.x; i < HW; i += blockDim.x) s += bp ? (double)ap[i] * bp[i] : (double)ap[i];
+    const double t = bsum_d(s, red);
+    if (threadIdx.x == 0) out[(long long)n * C + c] = (float)t;
+}
+extern "C" int dcvic_chan_reduce_f32(const float* a, long long a_bs, const float* b, long long b_bs, float* out, int N, int C, int HW, void* stream) {
+    DCVIC_CHECK_ARG(a && out && N > 0 && C > 0 && HW > 0, "chan_reduce: bad argument");
+    chan_reduce_kernel<<<N * C, 256, 0, (hipStream_t)stream>>>(a, a_bs, b, b_bs, out, C, HW);
+    DCVIC_CHECK_LAUNCH("chan_reduce");
+    return DCVIC_OK;
+}
+// out[j] (+)= sum_i in[i][j], i ascending (sum over the batch of per-image partials)
+extern "C" int dcvic_sum_rows_f32(const float* in, float* out, int rows, long long len, int accumulate, void* stream) {
+    DCVIC_CHECK_ARG(in && out && rows > 0 && len > 0, "sum_rows: bad argument");
+    slab_reduce_kernel<<<dcvic_cdiv(len, 256), 256, 0, (hipStream_t)stream>>>(in, out, len, rows, accumulate);
+    DCVIC_CHECK_LAUNCH("sum_rows");
+    return DCVIC_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ elementwise backward forms
+// op  0: d = g * act'(ref)      act in {relu, lrelu02, sigmoid, half_tanh: ref = OUTPUT y; swish, gelu: ref = INPUT x}
+// op  1: d = g * a                                   (product rule pieces)
+// op  2: d = g * sigmoid(a)                           NLAM: dt
+// op  3: d = g * a * s(1-s), s = sigmoid(b)           NLAM: d(att)
+// op  4: d = g * (1 + w * a)                          SFT: d(dec) given scale a
+// op  5: d = w * g * a                                SFT: d(scale) given dec a
+// op  6: d = w * g                                    SFT: d(shift) / plain scaling
+// op  7: d = g * (1 + s[n][c])                        beta-FT: dx   (a = per-channel vector [N or 1][C], a_bs = C or 0)
+// op  8: d = 2 * w * (a - b)                          MSE gradient (w = weight / numel)
+// op  9: d = w * (sigmoid(a) - t)                     BCE-with-logits gradient (t = `act` as 0 / 1)
+// op 10: d = a + b                                    gradient accumulation
+// op 11: d = a * w
+__global__ __launch_bounds__(256) void ew_bwd_kernel(int op, float* __restrict__ d, const float* __restrict__ g, const float* __restrict__ a,
+                                                     const float* __restrict__ b, long long len, float w, int act, int C, int HW, long long vec_bs) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= len) return;
+    float r;
+    switch (op) {
+        case 0: {
+            const float v = a[i];
+            float dv;
+            switch (act) {
+                case DCVIC_ACT_RELU: dv = v > 0.f ? 1.f : 0.f; break;
+                case DCVIC_ACT_LRELU02: dv = v > 0.f ? 1.f : 0.2f; break;
+                case DCVIC_ACT_SIGMOID: dv = v * (1.f - v); break;
+                case DCVIC_ACT_HALF_TANH: dv = 0.5f * (1.f - 4.f * v * v); break;            // y = tanh/2 -> dy/dx = (1 - tanh^2)/2
+                case DCVIC_ACT_SWISH: { const float s = 1.f / (1.f + expf(-v)); dv = s * (1.f + v * (1.f - s)); break; }
+                case DCVIC_ACT_GELU: { const float cdf = 0.5f * (1.f + erff(v * 0.70710678118654752440f));
+                                       dv = cdf + v * 0.39894228040143267794f * expf(-0.5f * v * v); break; }
+                default: dv = 1.f;
+            }
+            r = g[i] * dv; break;
+        }
+        case 1: r = g[i] * a[i]; break;
+        case 2: r = g[i] / (1.f + expf(-a[i])); break;
+        case 3: { const float s = 1.f / (1.f + expf(-b[i])); r = g[i] * a[i] * s * (1.f - s); break; }
+        case 4: r = g[i] * (1.f + w * a[i]); break;
+        case 5: r = w * g[i] * a[i]; break;
+        case 6: r = w * g[i]; break;
+        case 7: { const long long n = i / ((long long)C * HW); const int c = (int)((i / HW) % C); r = g[i] * (1.f + a[n * vec_bs + c]); break; }
+        case 8: r = 2.f * w * (a[i] - b[i]); break;
+        case 9: r = w * (1.f / (1.f + expf(-a[i])) - (float)act); break;
+        case 10: r = a[i] + b[i]; break;
+        default: r = a[i] * w;
+    }
+    d[i] = r;
+}
+extern "C" int dcvic_ew_bwd_f32(int op, float* d, const float* g, const float* a, const float* b, long long len, float w, int act, int C, int HW,
+                                long long vec_bs, void* stream) {
+    DCVIC_CHECK_ARG(d && len > 0 && op >= 0 && op <= 11, "ew_bwd: bad argument");
+    ew_bwd_kernel<<<dcvic_cdiv(len, 256), 256, 0, (hipStream_t)stream>>>(op, d, g, a, b, len, w, act, C, HW, vec_bs);
+    DCVIC_CHECK_LAUNCH("ew_bwd");
+    return DCVIC_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ GroupNorm backward
+// y = act(xh * gamma + beta), xh = (x - mean) * rstd over the group.  One workgroup per (n, group):
+//   dh = dy * act'(h);  dx = rstd * (dh*gamma - (S1 + xh * S2) / L),  S1 = sum dh*gamma, S2 = sum dh*gamma*xh
+//   per-image partials dgamma[n][c] = sum_p dh * xh, dbeta[n][c] = sum_p dh   (summed over n by dcvic_sum_rows_f32)
+__global__ __launch_bounds__(512) void groupnorm_bwd_kernel(const float* __restrict__ x, long long x_bs, const float* __restrict__ dy,
+                                                            long long dy_bs, float* __restrict__ dx, long long dx_bs,
+                                                            const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                            float* __restrict__ dgam, float* __restrict__ dbet, int C, int HW, int groups,
+                                                            float eps, int act) {
+    __shared__ double red[16];
+    const int n = blockIdx.x / groups, g = blockIdx.x % groups;
+    const int cg = C / groups;
+    const long long len = (long long)cg * HW;
+    const float* xp = x + (long long)n * x_bs + (long long)g * cg * HW;
+    const float* gp = dy + (long long)n * dy_bs + (long long)g * cg * HW;
+    float* dp = dx + (long long)n * dx_bs + (long long)g * cg * HW;
+    double s = 0.0, q = 0.0;
+    for (long long i = threadIdx.x; i < len; i += blockDim.x) { const double v = xp[i]; s += v; q += v * v; }
+    const double S = bsum_d(s, red), Q = bsum_d(q, red);
+    const double mean_d = S / (double)len;
+    const float mean = (float)mean_d;
+    const float var = (float)fmax(Q / (double)len - mean_d * mean_d, 0.0);
+    const float rstd = 1.0f / sqrtf(var + eps);
+    auto dh_of = [&](long long i, int c, float& xh) {
+        xh = (xp[i] - mean) * rstd;
+        const float h = xh * gamma[c] + beta[c];
+        float d = gp[i];
+        if (act == DCVIC_ACT_SWISH) { const float sg = 1.f / (1.f + expf(-h)); d *= sg * (1.f + h * (1.f - sg)); }
+        return d;
+    };
+    double s1 = 0.0, s2 = 0.0;
+    for (int cc = 0; cc < cg; ++cc) {
+        const int c = g * cg + cc;
+        double a1 = 0.0, a2 = 0.0;
+        for (int i = threadIdx.x; i < HW; i += blockDim.x) {
+            float xh;
+            const float d = dh_of((long long)cc * HW + i, c, xh);
+            a1 += (double)d; a2 += (double)d * xh;
+        }
+        const double A1 = bsum_d(a1, red), A2 = bsum_d(a2, red);
+        if (threadIdx.x == 0) { dbet[(long long)n * C + c] = (float)A1; dgam[(long long)n * C + c] = (float)A2; }
+        s1 += A1 * gamma[c]; s2 += A2 * gamma[c];
+    }
+    const float m1 = (float)(s1 / (double)len), m2 = (float)(s2 / (double)len);
+    for (long long i = threadIdx.x; i < len; i += blockDim.x) {
+        const int c = g * cg + (int)(i / HW);
+        float xh;
+        const float d = dh_of(i, c, xh);
+        dp[i] = rstd * (d * gamma[c] - (m1 + xh * m2));
+    }
+}
+extern "C" int dcvic_groupnorm_bwd_f32(const float* x, long long x_bs, const float* dy, long long dy_bs, float* dx, long long dx_bs,
+                                       const float* gamma, const float* beta, float* dgamma_part, float* dbeta_part, int N, int C, int HW,
+                                       int groups, float eps, int act, void* stream) {
+    DCVIC_CHECK_ARG(x && dy && dx && gamma && beta && dgamma_part && dbeta_part, "groupnorm_bwd: null pointer");
+    DCVIC_CHECK_ARG(C % groups == 0 && (act == DCVIC_ACT_NONE || act == DCVIC_ACT_SWISH), "groupnorm_bwd: C=%d groups=%d act=%d", C, groups, act);
+    groupnorm_bwd_kernel<<<N * groups, 512, 0, (hipStream_t)stream>>>(x, x_bs, dy, dy_bs, dx, dx_bs, gamma, beta, dgamma_part, dbeta_part, C, HW,
+                                                                      groups, eps, act);
+    DCVIC_CHECK_LAUNCH("groupnorm_bwd");
+    return DCVIC_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ channel LayerNorm backward
+// y[c] = xh[c]*gamma[c] + beta[c] per pixel over C.  Thread per pixel (coalesced across the wave); dgamma / dbeta partials per
+// workgroup [blocks][2][C] (reduced by dcvic_sum_rows_f32).
+__global__ __launch_bounds__(256) void layernorm_c_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ dx,
+                                                              const float* __restrict__ gamma, float* __restrict__ part, int C, int HW,
+                                                              int total, float eps) {
+    extern __shared__ float sred[];        // [4 waves][2][C]
+    const int gp = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool ok = gp < total;
+    const int n = ok ? gp / HW : 0, p = ok ? gp % HW : 0;
+    const float* xp = x + (long long)n * C * HW + p;
+    const float* gy = dy + (long long)n * C * HW + p;
+    float mean = 0.f, rstd = 0.f, m1 = 0.f, m2 = 0.f;
+    if (ok) {
+        float s = 0.f;
+        for (int c = 0; c < C; ++c) s += xp[(long long)c * HW];
+        mean = s / C;
+        float v = 0.f;
+        for (int c = 0; c < C; ++c) { const float d = xp[(long long)c * HW] - mean; v += d * d; }
+        rstd = 1.f / sqrtf(v / C + eps);
+        float a1 = 0.f, a2 = 0.f;
+        for (int c = 0; c < C; ++c) {
+            const float xh = (xp[(long long)c * HW] - mean) * rstd, d = gy[(long long)c * HW] * gamma[c];
+            a1 += d; a2 += d * xh;
+        }
+        m1 = a1 / C; m2 = a2 / C;
+    }
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    for (int c = 0; c < C; ++c) {
+        float xh = 0.f, d = 0.f;
+        if (ok) {
+            xh = (xp[(long long)c * HW] - mean) * rstd; d = gy[(long long)c * HW];
+            dx[(long long)n * C * HW + (long long)c * HW + p] = rstd * (d * gamma[c] - (m1 + xh * m2));
+        }
+        const float sg = wsum_f(d * xh), sb = wsum_f(d);
+        if (lane == 0) { sred[(w * 2 + 0) * C + c] = sg; sred[(w * 2 + 1) * C + c] = sb; }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 2 * C; i += blockDim.x) {
+        float t = 0.f;
+        for (int ww = 0; ww < 4; ++ww) t += sred[ww * 2 * C + i];
+        part[(long long)blockIdx.x * 2 * C + i] = t;
+    }
+}
+extern "C" int dcvic_layernorm_c_bwd_blocks(int N, int HW) { return dcvic_cdiv((long long)N * HW, 256); }
+extern "C" int dcvic_layernorm_c_bwd_f32(const float* x, const float* dy, float* dx, const float* gamma, float* part, int N, int C, int HW,
+                                         float eps, void* stream) {
+    DCVIC_CHECK_ARG(x && dy && dx && gamma && part && C <= 1024, "layernorm_c_bwd: bad argument");
+    const int blocks = dcvic_cdiv((long long)N * HW, 256);
+    layernorm_c_bwd_kernel<<<blocks, 256, (size_t)8 * C * sizeof(float), (hipStream_t)stream>>>(x, dy, dx, gamma, part, C, HW, N * HW, eps);
+    DCVIC_CHECK_LAUNCH("layernorm_c_bwd");
+    return DCVIC_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ column softmax backward
+// P, dP: [N][C][Pn] with the softmax over C (the attention score matrix stored [key][query]).  dS = scale * P * (dP - sum_c P dP)
+__global__ __launch_bounds__(256) void softmax_c_bwd_kernel(const float* __restrict__ P, const float* __restrict__ dP, float* __restrict__ dS,
+                                                            int C, int Pn, float scale) {
+    const int n = blockIdx.y, p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= Pn) return;
+    const long long base = (long long)n * C * Pn + p;
+    float dot = 0.f;
+    for (int c = 0; c < C; ++c) dot += P[base + (long long)c * Pn] * dP[base + (long long)c * Pn];
+    for (int c = 0; c < C; ++c) { const long long i = base + (long long)c * Pn; dS[i] = scale * P[i] * (dP[i] - dot); }
+}
+extern "C" int dcvic_softmax_c_bwd_f32(const float* P, const float* dP, float* dS, int N, int C, int Pn, float scale, void* stream) {
+    DCVIC_CHECK_ARG(P && dP && dS && N > 0 && N <= 65535, "softmax_c_bwd: bad argument");
+    dim3 grid(dcvic_cdiv(Pn, 256), N);
+    softmax_c_bwd_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(P, dP, dS, C, Pn, scale);
+    DCVIC_CHECK_LAUNCH("softmax_c_bwd");
+    return DCVIC_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ Swin window attention backward
+// Forward (swin.hip / swinir_layers.py:118-148): per (image, window, head): S = (q*scale) k^T + bias[rel] (+ mask), P = softmax_j S,
+// o = P v, on the cyclically shifted NCHW qkv map.  One workgroup (64 threads: thread = query token i) per (n, window, head).
+// Outputs: dqkv [N][3C][H][W] (written at the un-shifted positions) and the per-(n, window) score gradients dSp[nw][head][64][64]
+// from which dcvic_swin_bias_grad_f32 accumulates the relative-position table gradient in a fixed order.
+__global__ __launch_bounds__(64) void swin_attn_bwd_kernel(const float* __restrict__ qkv, const float* __restrict__ dout, float* __restrict__ dqkv,
+                                                           const float* __restrict__ table, float* __restrict__ dSp, int C, int H, int W,
+                                                           int heads, int ws, int shift) {
+    constexpr int MAXD = 16;
+    __shared__ float Ks[64 * MAXD], Vs[64 * MAXD], Qs[64 * MAXD], dOs[64 * MAXD], dSs[64 * 65];
+    const int hd = C / heads, T = ws * ws;
+    const int nWx = W / ws, nWy = H / ws;
+    int b = blockIdx.x;
+    const int head = b % heads; b /= heads;
+    const int win = b % (nWx * nWy); const int n = b / (nWx * nWy);
+    const int wy = win / nWx, wx = win % nWx;
+    const int i = threadIdx.x;                 // token in window
+    const int ty = i / ws, tx = i % ws;
+    // shifted-frame coordinates -> source coordinates (torch.roll(x, -shift))
+    const int sy = wy * ws + ty, sx = wx * ws + tx;
+    const int yy = (sy + shift) % H, xx = (sx + shift) % W;
+    const long long HWl = (long long)H * W;
+    const long long pix = (long long)yy * W + xx;
+    const float* base = qkv + (long long)n * 3 * C * HWl;
+    const float scale = rsqrtf((float)hd);
+    for (int d = 0; d < hd; ++d) {
+        Qs[i * MAXD + d] = base[(long long)(head * hd + d) * HWl + pix];
+        Ks[i * MAXD + d] = base[(long long)(C + head * hd + d) * HWl + pix];
+        Vs[i * MAXD + d] = base[(long long)(2 * C + head * hd + d) * HWl + pix];
+        dOs[i * MAXD + d] = dout[(long long)n * C * HWl + (long long)(head * hd + d) * HWl + pix];
+    }
+    __syncthreads();
+    // region label of a shifted-frame position (swinir_layers.py:216-237)
+    auto label = [&](int y, int x) {
+        const int ry = y < H - ws ? 0 : (y < H - shift ? 1 : 2), rx = x < W - ws ? 0 : (x < W - shift ? 1 : 2);
+        return ry * 3 + rx;
+    };
+    const int li = shift > 0 ? label(sy, sx) : 0;
+    float Srow[64];
+    float mx = -INFINITY;
+    for (int j = 0; j < T; ++j) {
+        float s = 0.f;
+        for (int d = 0; d < hd; ++d) s = fmaf(Qs[i * MAXD + d] * scale, Ks[j * MAXD + d], s);
+        const int jy = j / ws, jx = j % ws;
+        const int rel = (ty - jy + ws - 1) * (2 * ws - 1) + (tx - jx + ws - 1);
+        s += table[rel * heads + head];
+        if (shift > 0 && label(wy * ws + jy, wx * ws + jx) != li) s += -100.f;
+        Srow[j] = s; mx = fmaxf(mx, s);
+    }
+    float den = 0.f;
+    for (int j = 0; j < T; ++j) { Srow[j] = expf(Srow[j] - mx); den += Srow[j]; }
+    const float inv = 1.f / den;
+    // dP[j] = dO_i . v_j ; dS = P (dP - sum P dP)
+    float dPr[64];
+    float dot = 0.f;
+    for (int j = 0; j < T; ++j) {
+        float a = 0.f;
+        for (int d = 0; d < hd; ++d) a = fmaf(dOs[i * MAXD + d], Vs[j * MAXD + d], a);
+        Srow[j] *= inv; dPr[j] = a; dot += Srow[j] * a;
+    }
+    float dq[MAXD];
+    for (int d = 0; d < hd; ++d) dq[d] = 0.f;
+    float* dSout = dSp + (((long long)(n * nWx * nWy + win)) * heads + head) * T * T;
+    for (int j = 0; j < T; ++j) {
+        const float ds = Srow[j] * (dPr[j] - dot);
+        dSs[i * 65 + j] = ds;
+        dSout[i * T + j] = ds;
+        for (int d = 0; d < hd; ++d) dq[d] = fmaf(ds, Ks[j * MAXD + d], dq[d]);
+    }
+    // P is needed by the dV accumulation of other threads: keep it in Qs' place after q has been consumed -> use a second pass
+    __syncthreads();
+    float* dbase = dqkv + (long long)n * 3 * C * HWl;
+    for (int d = 0; d < hd; ++d) dbase[(long long)(head * hd + d) * HWl + pix] = dq[d] * scale;
+    // dK_i = sum_t dS[t][i] * q_t * scale ; dV_i = sum_t P[t][i] * dO_t  (thread i now acts as key / value token i)
+    float dk[MAXD], dv[MAXD];
+    for (int d = 0; d < hd; ++d) { dk[d] = 0.f; dv[d] = 0.f; }
+    // P[t][i] recomputed from dS is not possible: stage P through LDS column by column
+    __shared__ float Ps[64 * 65];
+    for (int j = 0; j < T; ++j) Ps[i * 65 + j] = Srow[j];
+    __syncthreads();
+    for (int t = 0; t < T; ++t) {
+        const float ds = dSs[t * 65 + i], pp = Ps[t * 65 + i];
+        for (int d = 0; d < hd; ++d) {
+            dk[d] = fmaf(ds, Qs[t * MAXD + d] * scale, dk[d]);
+            dv[d] = fmaf(pp, dOs[t * MAXD + d], dv[d]);
+        }
+    }
+    for (int d = 0; d < hd; ++d) {
+        dbase[(long long)(C + head * hd + d) * HWl + pix] = dk[d];
+        dbase[(long long)(2 * C + head * hd + d) * HWl + pix] = dv[d];
+    }
+}
+// dtable[rel][head] (+)= sum over (n, window) ascending, then over the (i, j) pairs of that relative offset ascending
+__global__ void swin_bias_grad_kernel(const float* __restrict__ dSp, float* __restrict__ dtable, int nwin_total, int heads, int ws, int accumulate) {
+    const int T = ws * ws, R = (2 * ws - 1) * (2 * ws - 1);
+    const int id = blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= R * heads) return;
+    const int rel = id / heads, head = id % heads;
+    const int dy = rel / (2 * ws - 1) - (ws - 1), dx = rel % (2 * ws - 1) - (ws - 1);
+    float s = accumulate ? dtable[id] : 0.f;
+    for (int w = 0; w < nwin_total; ++w) {
+        const float* D = dSp + ((long long)w * heads + head) * T * T;
+        for (int i = 0; i < T; ++i) {
+            const int jy = i / ws - dy, jx = i % ws - dx;
+            if (jy >= 0 && jy < ws && jx >= 0 && jx < ws) s += D[i * T + jy * ws + jx];
+        }
+    }
+    dtable[id] = s;
+}
+extern "C" int dcvic_swin_attn_bwd_f32(const float* qkv, const float* dout, float* dqkv, const float* table, float* dtable, float* dS_workspace,
+                                       int N, int C, int H, int W, int heads, int ws, int shift, int accumulate, void* stream) {
+    DCVIC_CHECK_ARG(qkv && dout && dqkv && table && dtable && dS_workspace, "swin_attn_bwd: null pointer");
+    DCVIC_CHECK_ARG(ws == 8 && C % heads == 0 && C / heads <= 16 && H % ws == 0 && W % ws == 0, "swin_attn_bwd: ws=%d C=%d heads=%d", ws, C, heads);
+    const int nwin = N * (H / ws) * (W / ws);
+    swin_attn_bwd_kernel<<<nwin * heads, 64, 0, (hipStream_t)stream>>>(qkv, dout, dqkv, table, dS_workspace, C, H, W, heads, ws, shift);
+    DCVIC_CHECK_LAUNCH("swin_attn_bwd");
+    const int R = (2 * ws - 1) * (2 * ws - 1);
+    swin_bias_grad_kernel<<<dcvic_cdiv(R * heads, 64), 64, 0, (hipStream_t)stream>>>(dS_workspace, dtable, nwin, heads, ws, accumulate);
+    DCVIC_CHECK_LAUNCH("swin_bias_grad");
+    return DCVIC_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ losses
+// deterministic two-stage sums: stage 1 per-workgroup fp64 partials, stage 2 one workgroup in index order
+__global__ __launch_bounds__(256) void loss_partial_kernel(int kind, const float* __restrict__ a, const float* __restrict__ b, long long len,
+                                                           int t, double* __restrict__ part) {
+    __shared__ double red[16];
+    double s = 0.0;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < len; i += (long long)gridDim.x * blockDim.x) {
+        if (kind == 0) { const double d = (double)a[i] - (double)b[i]; s += d * d; }                 // squared error
+        else if (kind == 1) { const float x = a[i]; s += (double)(fmaxf(x, 0.f) - x * (float)t + log1pf(expf(-fabsf(x)))); }   // BCE-with-logits
+        else if (kind == 2) { const double v = a[i]; s += v * v; }                                  // sum of squares
+        else s += (double)a[i];                                                                     // plain sum
+    }
+    const double T = bsum_d(s, red);
+    if (threadIdx.x == 0) part[blockIdx.x] = T;
+}
+__global__ void loss_final_kernel(const double* __restrict__ part, int n, double scale, float* __restrict__ out) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        double s = 0.0;
+        for (int i = 0; i < n; ++i) s += part[i];
+        out[0] = (float)(s * scale);
+    }
+}
+// out[0] = scale * sum_i f(a[i], b[i] | t); kind 0: (a-b)^2, 1: BCE-with-logits(a, target t), 2: a^2, 3: a.  workspace: 1024 doubles
+extern "C" int dcvic_reduce_loss_f32(int kind, const float* a, const float* b, long long len, int target, double scale, float* out,
+                                     double* workspace, void* stream) {
+    DCVIC_CHECK_ARG(a && out && workspace && len > 0 && kind >= 0 && kind <= 3, "reduce_loss: bad argument");
+    const int blocks = (int)min((long long)1024, (long long)dcvic_cdiv(len, 256));
+    loss_partial_kernel<<<blocks, 256, 0, (hipStream_t)stream>>>(kind, a, b, len, target, workspace);
+    loss_final_kernel<<<1, 64, 0, (hipStream_t)stream>>>(workspace, blocks, scale, out);
+    DCVIC_CHECK_LAUNCH("reduce_loss");
+    return DCVIC_OK;
+}
+// cross entropy over the channel axis of logits [N][C][HW] against int64 targets [N][HW]:
+//   nll[n][p] = logsumexp_c - logit[target];  dlogits = w * (softmax - onehot)   (w = weight / (N*HW))
+__global__ __launch_bounds__(256) void ce_kernel(const float* __restrict__ logits, const int64_t* __restrict__ target, float* __restrict__ nll,
+                                                 float* __restrict__ dlogits, int C, int HW, float w) {
+    const int n = blockIdx.y, p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= HW) return;
+    const float* lp = logits + (long long)n * C * HW + p;
+    float mx = -INFINITY;
+    for (int c = 0; c < C; ++c) mx = fmaxf(mx, lp[(long long)c * HW]);
+    float den = 0.f;
+    for (int c = 0; c < C; ++c) den += expf(lp[(long long)c * HW] - mx);
+    const int t = (int)target[(long long)n * HW + p];
+    nll[(long long)n * HW + p] = logf(den) + mx - lp[(long long)t * HW];
+    if (dlogits) {
+        float* dp = dlogits + (long long)n * C * HW + p;
+        const float inv = 1.f / den;
+        for (int c = 0; c < C; ++c) dp[(long long)c * HW] = w * (expf(lp[(long long)c * HW] - mx) * inv - (c == t ? 1.f : 0.f));
+    }
+}
+extern "C" int dcvic_cross_entropy_f32(const float* logits, const int64_t* target, float* nll, float* dlogits, int N, int C, int HW, float w,
+                                       void* stream) {
+    DCVIC_CHECK_ARG(logits && target && nll && N > 0 && N <= 65535, "cross_entropy: bad argument");
+    dim3 grid(dcvic_cdiv(HW, 256), N);
+    ce_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(logits, target, nll, dlogits, C, HW, w);
+    DCVIC_CHECK_LAUNCH("cross_entropy");
+    return DCVIC_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ optimizer
+// torch.optim.Adam (no amsgrad, weight_decay 0): m = b1 m + (1-b1) g; v = b2 v + (1-b2) g^2;
+// p -= lr / (1 - b1^t) * m / (sqrt(v) / sqrt(1 - b2^t) + eps).   gscale = gradient-clipping factor applied to g first.
+__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+                                                   long long len, float lr, float b1, float b2, float eps, float bc1, float bc2s,
+                                                   const float* __restrict__ gscale) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= len) return;
+    const float gs = gscale ? gscale[0] : 1.f;
+    const float gi = g[i] * gs;
+    const float mi = b1 * m[i] + (1.f - b1) * gi;
+    const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+    m[i] = mi; v[i] = vi;
+    const float denom = sqrtf(vi) / bc2s + eps;
+    p[i] = p[i] - (lr / bc1) * (mi / denom);
+}
+extern "C" int dcvic_adam_step_f32(float* p, const float* g, float* m, float* v, long long len, float lr, float beta1, float beta2, float eps,
+                                   int step, const float* gscale, void* stream) {
+    DCVIC_CHECK_ARG(p && g && m && v && len > 0 && step >= 1, "adam: bad argument");
+    const float bc1 = 1.f - powf(beta1, (float)step), bc2s = sqrtf(1.f - powf(beta2, (float)step));
+    adam_kernel<<<dcvic_cdiv(len, 256), 256, 0, (hipStream_t)stream>>>(p, g, m, v, len, lr, beta1, beta2, eps, bc1, bc2s, gscale);
+    DCVIC_CHECK_LAUNCH("adam");
+    return DCVIC_OK;
+}
+// clip_grad_norm_: gscale[0] = min(1, max_norm / (sqrt(sumsq[0]) + 1e-6))
+__global__ void clip_scale_kernel(const float* __restrict__ sumsq, float max_norm, float* __restrict__ gscale) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) { const float c = max_norm / (sqrtf(sumsq[0]) + 1e-6f); gscale[0] = c < 1.f ? c : 1.f; }
+}
+extern "C" int dcvic_clip_scale_f32(const float* sumsq, float max_norm, float* gscale, void* stream) {
+    DCVIC_CHECK_ARG(sumsq && gscale, "clip_scale: null pointer");
+    clip_scale_kernel<<<1, 64, 0, (hipStream_t)stream>>>(sumsq, max_norm, gscale);
+    DCVIC_CHECK_LAUNCH("clip_scale");
+    return DCVIC_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ resampling
+// nearest x2 upsample (model.py:53-57 F.interpolate) and its adjoint (sum of each 2x2 block)
+__global__ __launch_bounds__(256) void resample2_kernel(int down, const float* __restrict__ in, float* __restrict__ out, long long planes, int H, int W) {
+    // H, W: LOW resolution
+    const long long total = down ? planes * H * W : planes * 4 * H * W;
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    if (down) {
+        const long long pl = i / ((long long)H * W); const int r = (int)(i % ((long long)H * W)); const int y = r / W, x = r % W;
+        const float* ip = in + pl * 4 * H * W + (long long)(2 * y) * 2 * W + 2 * x;
+        out[i] = (ip[0] + ip[1]) + (ip[2 * W] + ip[2 * W + 1]);
+    } else {
+        const long long pl = i / ((long long)4 * H * W); const int r = (int)(i % ((long long)4 * H * W)); const int y = r / (2 * W), x = r % (2 * W);
+        out[i] = in[pl * H * W + (long long)(y >> 1) * W + (x >> 1)];
+    }
+}
+extern "C" int dcvic_resample2_f32(int down, const float* in, float* out, long long planes, int Hlow, int Wlow, void* stream) {
+    DCVIC_CHECK_ARG(in && out && planes > 0, "resample2: bad argument");
+    const long long total = down ? planes * Hlow * Wlow : planes * 4 * Hlow * Wlow;
+    resample2_kernel<<<dcvic_cdiv(total, 256), 256, 0, (hipStream_t)stream>>>(down, in, out, planes, Hlow, Wlow);
+    DCVIC_CHECK_LAUNCH("resample2");
+    return DCVIC_OK;
+}

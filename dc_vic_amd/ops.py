@@ -178,6 +178,26 @@ class ConvPlan:
         else:
             raise ValueError(kind)
 
+    @classmethod
+    def from_phases2(cls, wphases: Sequence[Tensor]) -> "ConvPlan":
+        """Four 2x2 sub-pixel convolutions writing the (py, px) phases of a x2-sized output (order (0,0), (0,1), (1,0), (1,1));
+        phase (py, px) reads low-resolution rows {m-1, m} (py = 0) or {m, m+1} (py = 1), same for columns.  This is the
+        shape of `nearest x2 + conv3x3` AND of ConvTranspose2d(k4, s2, p1) -- the data gradient of a Conv2d(k4, s2, p1)."""
+        self = cls.__new__(cls)
+        w0 = wphases[0]
+        self.kind, self.stride, self.pad, self.upsample = "conv", 1, (1, 1), True
+        self.bias = None
+        self._w = None
+        self.Cout, self.Cin, self.KH, self.KW = w0.shape[0], w0.shape[1], 3, 3
+        self.ups_phases = True
+        self.phases, self._wphase = [], []
+        for (py, px), wp in zip(((0, 0), (0, 1), (1, 0), (1, 1)), wphases):
+            d = ConvDesc()
+            check(lib().dcvic_conv_desc_init(C.byref(d), self.Cin, self.Cout, 2, 2, 1, 1 - py, 1 - px, 0), "conv_desc_init")
+            self.phases.append([d, {}, py, px])
+            self._wphase.append(wp.detach().contiguous())
+        return self
+
     @staticmethod
     def _pack(d: ConvDesc, w: Tensor) -> Tensor:
         nbytes = lib().dcvic_conv_packed_bytes(C.byref(d))

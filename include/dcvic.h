@@ -265,6 +265,54 @@ int dcvic_rans_decode_batch_host(const dcvic_cdf_tables*, dcvic_rans_decoder* co
                                  const int32_t* indexes, int n_streams, long long n_sym, int32_t* symbols,
                                  int threads);
 
+/* ==========================================================================================
+ * Training step.  Replaces torch autograd / torch.optim on the reference's
+ * src/trainer/dual_cond_gan_distortion_vq_code_trainer.py:135-300 path.  Data gradients of convolutions are
+ * dcvic_conv2d_f32 launches on transposed / flipped weights; these are the remaining backward pieces.  All reductions
+ * run in a fixed order (no atomics): ranks and reruns agree bit for bit.
+ */
+/* Weight gradient dW[m][c][ky][kx] = sum_{n,oy,ox} G[n][m][oy][ox] * X[n][c][oy*s+ky-pt][ox*s+kx-pl]  (fp32 MFMA, split over
+ * pixel slabs, partials reduced in ascending slab order).  Conv2d: G = dY, X = input -> [Cout][Cin][KH][KW];
+ * ConvTranspose2d(stride s): G = input, X = dY -> [Cin][Cout][KH][KW].  workspace: dcvic_conv_wgrad_workspace_floats(). */
+long long dcvic_conv_wgrad_workspace_floats(int N, int M, int Cx, int KH, int KW, int Hg, int* slabs_out);
+int dcvic_conv_wgrad_f32(const float* G, long long g_bs, int M, int Hg, int Wg, const float* X, long long x_bs, int Cx,
+                         int Hx, int Wx, int N, int KH, int KW, int stride, int pt, int pl, float* dW, int accumulate,
+                         float* workspace, void* stream);
+/* out[n][c] = sum_p a[n][c][p] * (b ? b[n][c][p] : 1)  (bias / beta-FT vector gradients), fp64 accumulation. */
+int dcvic_chan_reduce_f32(const float* a, long long a_bs, const float* b, long long b_bs, float* out, int N, int C, int HW, void* stream);
+/* out[j] (+)= sum_i in[i][j], i ascending. */
+int dcvic_sum_rows_f32(const float* in, float* out, int rows, long long len, int accumulate, void* stream);
+/* Elementwise backward forms (op table in csrc/train.hip): activation derivatives, NLAM / SFT / beta-FT gates, MSE and
+ * BCE-with-logits gradients, accumulation, scaling. */
+int dcvic_ew_bwd_f32(int op, float* d, const float* g, const float* a, const float* b, long long len, float w, int act, int C, int HW,
+                     long long vec_bs, void* stream);
+/* GroupNorm(+swish) backward: dx and per-image partials dgamma_part / dbeta_part [N][C]. */
+int dcvic_groupnorm_bwd_f32(const float* x, long long x_bs, const float* dy, long long dy_bs, float* dx, long long dx_bs,
+                            const float* gamma, const float* beta, float* dgamma_part, float* dbeta_part, int N, int C, int HW,
+                            int groups, float eps, int act, void* stream);
+/* Channel LayerNorm backward: dx and per-workgroup partials part[blocks][2][C] (dgamma | dbeta). */
+int dcvic_layernorm_c_bwd_blocks(int N, int HW);
+int dcvic_layernorm_c_bwd_f32(const float* x, const float* dy, float* dx, const float* gamma, float* part, int N, int C, int HW,
+                              float eps, void* stream);
+/* Backward of the column softmax of dcvic_softmax_c_f32: dS = scale * P * (dP - sum_c P dP). */
+int dcvic_softmax_c_bwd_f32(const float* P, const float* dP, float* dS, int N, int C, int Pn, float scale, void* stream);
+/* Backward of dcvic_swin_attn_f32: dqkv and the relative-position table gradient (dS_workspace: N*windows*heads*64*64 floats). */
+int dcvic_swin_attn_bwd_f32(const float* qkv, const float* dout, float* dqkv, const float* table, float* dtable, float* dS_workspace,
+                            int N, int C, int H, int W, int heads, int ws, int shift, int accumulate, void* stream);
+/* out[0] = scale * sum f: kind 0 (a-b)^2 (src/losses/distortion_loss.py), 1 BCE-with-logits(a, target) (gan_loss.py), 2 a^2
+ * (clip_grad_norm_).  Two-stage fp64 sum in index order.  workspace: 1024 doubles. */
+int dcvic_reduce_loss_f32(int kind, const float* a, const float* b, long long len, int target, double scale, float* out,
+                          double* workspace, void* stream);
+/* Cross entropy over the channel axis (src/losses/cross_entropy_loss.py): per-pixel nll and dlogits = w * (softmax - onehot). */
+int dcvic_cross_entropy_f32(const float* logits, const int64_t* target, float* nll, float* dlogits, int N, int C, int HW, float w, void* stream);
+/* torch.optim.Adam step on a flat parameter buffer; gscale (device scalar or NULL) multiplies the gradient first. */
+int dcvic_adam_step_f32(float* p, const float* g, float* m, float* v, long long len, float lr, float beta1, float beta2, float eps,
+                        int step, const float* gscale, void* stream);
+/* gscale[0] = min(1, max_norm / (sqrt(sumsq[0]) + 1e-6))   (torch.nn.utils.clip_grad_norm_). */
+int dcvic_clip_scale_f32(const float* sumsq, float max_norm, float* gscale, void* stream);
+/* Nearest x2 upsample (down = 0) and its adjoint, the 2x2 block sum (down = 1), on `planes` planes of Hlow x Wlow. */
+int dcvic_resample2_f32(int down, const float* in, float* out, long long planes, int Hlow, int Wlow, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,329 @@
+"""Training step on a real MI355X: every backward kernel against torch-CPU autograd of the same op, the
+differentiable sub-network forwards against torch autograd over the CPU oracle (per-parameter gradients), and one full
+G + D optimisation step (losses, clipped Adam update) against the oracle's torch restatement.
+Tolerances: fp32 MFMA fmaf chains vs MKL summation order; gradients are compared relative to the tensor's max magnitude."""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+DEV = "cuda:0"
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    return torch.randn(shape, generator=torch.Generator().manual_seed(seed)) * scale
+
+
+def relclose(a, b, tol=2e-4, what=""):
+    a = a.detach().cpu().double() if isinstance(a, torch.Tensor) else torch.as_tensor(a).double()
+    b = b.detach().cpu().double() if isinstance(b, torch.Tensor) else torch.as_tensor(b).double()
+    assert a.shape == b.shape, (what, a.shape, b.shape)
+    den = float(b.abs().max()) + 1e-12
+    err = float((a - b).abs().max()) / den
+    assert err <= tol, f"{what}: max |diff| / max |ref| = {err:.3e} > {tol}"
+    return err
+
+
+# ------------------------------------------------------------------------------------------------ kernels
+@pytest.mark.parametrize("case", [
+    dict(N=2, Ci=40, Co=72, H=20, W=33, k=3, s=1, p=1), dict(N=3, Ci=192, Co=96, H=16, W=16, k=1, s=1, p=0),
+    dict(N=2, Ci=11, Co=64, H=32, W=48, k=4, s=2, p=1), dict(N=2, Ci=64, Co=130, H=17, W=17, k=4, s=1, p=1),
+    dict(N=1, Ci=448, Co=256, H=32, W=32, k=3, s=1, p=1)])
+def test_conv_wgrad_and_dgrad(case):
+    """dW (fp32 MFMA, slab-split, fixed-order reduce) and dX (forward kernel on transposed / flipped weights or the four
+    sub-pixel phases for k4/s2) of Conv2d vs torch autograd."""
+    from dc_vic_amd import ops
+    from dc_vic_amd.layers import Conv2d
+    from dc_vic_amd.train import autograd as A
+    c = case
+    x, w = rnd(c["N"], c["Ci"], c["H"], c["W"], seed=1), rnd(c["Co"], c["Ci"], c["k"], c["k"], seed=2, scale=0.1)
+    b = rnd(c["Co"], seed=3, scale=0.1)
+    xr, wr, br = x.clone().requires_grad_(True), w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    y = F.conv2d(xr, wr, br, stride=c["s"], padding=c["p"])
+    g = rnd(*y.shape, seed=4)
+    y.backward(g)
+    mod = Conv2d(c["Ci"], c["Co"], c["k"], c["s"], c["p"]).to(DEV)
+    mod.weight.data.copy_(w); mod.bias.data.copy_(b)
+    grp = A.ParamGroup([mod], DEV)
+    ctx = A.Ctx([grp])
+    xv = A.Var(x.to(DEV))
+    out = A.conv(ctx, xv, mod)
+    relclose(out.data, y, 1e-5, "conv forward")
+    out.grad = g.to(DEV)
+    ctx.backward()
+    relclose(grp.grad_of(mod.weight), wr.grad, 2e-5, "dW")
+    relclose(grp.grad_of(mod.bias), br.grad, 2e-5, "db")
+    relclose(xv.grad, xr.grad, 2e-5, "dX")
+    # accumulation: a second backward adds into the flat gradient buffer
+    ctx = A.Ctx([grp]); xv = A.Var(x.to(DEV)); out = A.conv(ctx, xv, mod); out.grad = g.to(DEV); ctx.backward()
+    relclose(grp.grad_of(mod.weight), 2 * wr.grad, 2e-5, "dW accumulated")
+
+
+def test_conv_transpose_and_upsample_grads():
+    from dc_vic_amd.layers import Conv2d, ConvTranspose2d, Linear
+    from dc_vic_amd.train import autograd as A
+    # ConvTranspose2d(k5, s2, p2, op1) -- elic up_conv
+    x, w, b = rnd(2, 48, 9, 12, seed=5), rnd(48, 40, 5, 5, seed=6, scale=0.1), rnd(40, seed=7, scale=0.1)
+    xr, wr, br = x.clone().requires_grad_(True), w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    y = F.conv_transpose2d(xr, wr, br, stride=2, padding=2, output_padding=1)
+    g = rnd(*y.shape, seed=8); y.backward(g)
+    mod = ConvTranspose2d(48, 40, 5, 2, 2, 1).to(DEV)
+    mod.weight.data.copy_(w); mod.bias.data.copy_(b)
+    grp = A.ParamGroup([mod], DEV); ctx = A.Ctx([grp]); xv = A.Var(x.to(DEV))
+    out = A.conv(ctx, xv, mod); relclose(out.data, y, 1e-5, "convT forward")
+    out.grad = g.to(DEV); ctx.backward()
+    relclose(grp.grad_of(mod.weight), wr.grad, 2e-5, "convT dW"); relclose(grp.grad_of(mod.bias), br.grad, 2e-5, "convT db")
+    relclose(xv.grad, xr.grad, 2e-5, "convT dX")
+    # frozen nearest-x2 + conv3x3 (ldm Upsample): data gradient only
+    x, w, b = rnd(2, 32, 8, 10, seed=9), rnd(32, 32, 3, 3, seed=10, scale=0.1), rnd(32, seed=11, scale=0.1)
+    xr = x.clone().requires_grad_(True)
+    y = F.conv2d(F.interpolate(xr, scale_factor=2.0, mode="nearest"), w, b, padding=1)
+    g = rnd(*y.shape, seed=12); y.backward(g)
+    mod = Conv2d(32, 32, 3, 1, 1, upsample=True).to(DEV)
+    mod.weight.data.copy_(w); mod.bias.data.copy_(b)
+    ctx = A.Ctx([]); xv = A.Var(x.to(DEV)); out = A.conv(ctx, xv, mod)
+    relclose(out.data, y, 1e-5, "upsample conv forward"); out.grad = g.to(DEV); ctx.backward()
+    relclose(xv.grad, xr.grad, 2e-5, "upsample conv dX")
+    # Linear on a [B, C, 1, 1] vector map with fused ReLU (the beta-conditioning MLPs)
+    x, w, b = rnd(5, 42, 1, 1, seed=13), rnd(128, 42, seed=14, scale=0.2), rnd(128, seed=15, scale=0.1)
+    xr, wr, br = x.clone().requires_grad_(True), w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    y = F.relu(F.linear(xr.flatten(1), wr, br)); g = rnd(*y.shape, seed=16); y.backward(g)
+    mod = Linear(42, 128).to(DEV); mod.weight.data.copy_(w); mod.bias.data.copy_(b)
+    grp = A.ParamGroup([mod], DEV); ctx = A.Ctx([grp]); xv = A.Var(x.to(DEV))
+    from dc_vic_amd import ops
+    out = A.conv(ctx, xv, mod, act=ops.ACT_RELU); out.grad = g.view(5, 128, 1, 1).to(DEV); ctx.backward()
+    relclose(grp.grad_of(mod.weight), wr.grad, 2e-5, "linear dW"); relclose(xv.grad.flatten(1), xr.grad.flatten(1), 2e-5, "linear dX")
+
+
+def test_norm_and_activation_backward():
+    from dc_vic_amd import ops
+    from dc_vic_amd.layers import GroupNorm, LayerNormC
+    from dc_vic_amd.train import autograd as A
+    for C, H, W, act in ((64, 9, 7, ops.ACT_SWISH), (704, 8, 8, ops.ACT_SWISH), (128, 16, 16, ops.ACT_NONE)):
+        x, ga, be = rnd(2, C, H, W, seed=20, scale=1.5) + 0.3, 1 + 0.1 * rnd(C, seed=21), 0.1 * rnd(C, seed=22)
+        xr, gr, br = x.clone().requires_grad_(True), ga.clone().requires_grad_(True), be.clone().requires_grad_(True)
+        y = F.group_norm(xr, 32, gr, br, eps=1e-6)
+        y = y * torch.sigmoid(y) if act == ops.ACT_SWISH else y
+        g = rnd(*y.shape, seed=23); y.backward(g)
+        mod = GroupNorm(C).to(DEV); mod.weight.data.copy_(ga); mod.bias.data.copy_(be)
+        grp = A.ParamGroup([mod], DEV); ctx = A.Ctx([grp]); xv = A.Var(x.to(DEV))
+        out = A.group_norm(ctx, xv, mod, act=act); out.grad = g.to(DEV); ctx.backward()
+        relclose(xv.grad, xr.grad, 5e-5, f"GN dx C={C}"); relclose(grp.grad_of(mod.weight), gr.grad, 5e-5, "GN dgamma")
+        relclose(grp.grad_of(mod.bias), br.grad, 5e-5, "GN dbeta")
+    x, ga, be = rnd(2, 128, 8, 24, seed=24), 1 + 0.1 * rnd(128, seed=25), 0.1 * rnd(128, seed=26)
+    xr, gr, br = x.clone().requires_grad_(True), ga.clone().requires_grad_(True), be.clone().requires_grad_(True)
+    y = F.layer_norm(xr.permute(0, 2, 3, 1), (128,), gr, br, eps=1e-5).permute(0, 3, 1, 2)
+    g = rnd(*y.shape, seed=27); y.backward(g)
+    mod = LayerNormC(128).to(DEV); mod.weight.data.copy_(ga); mod.bias.data.copy_(be)
+    grp = A.ParamGroup([mod], DEV); ctx = A.Ctx([grp]); xv = A.Var(x.to(DEV))
+    out = A.layer_norm_c(ctx, xv, mod); out.grad = g.to(DEV).contiguous(); ctx.backward()
+    relclose(xv.grad, xr.grad, 5e-5, "LN dx"); relclose(grp.grad_of(mod.weight), gr.grad, 5e-5, "LN dgamma"); relclose(grp.grad_of(mod.bias), br.grad, 5e-5, "LN dbeta")
+    acts = {ops.ACT_RELU: F.relu, ops.ACT_LRELU02: lambda t: F.leaky_relu(t, 0.2), ops.ACT_SIGMOID: torch.sigmoid, ops.ACT_SWISH: F.silu,
+            ops.ACT_GELU: F.gelu, ops.ACT_HALF_TANH: lambda t: 0.5 * torch.tanh(t)}
+    for a, fn in acts.items():
+        x = rnd(2, 8, 6, 5, seed=28 + a); xr = x.clone().requires_grad_(True)
+        y = fn(xr); g = rnd(*y.shape, seed=40); y.backward(g)
+        ctx = A.Ctx([]); xv = A.Var(x.to(DEV)); out = A.activation(ctx, xv, a); out.grad = g.to(DEV); ctx.backward()
+        relclose(out.data, y, 1e-5, f"act {a} fwd"); relclose(xv.grad, xr.grad, 2e-5, f"act {a} bwd")
+
+
+def test_gates_and_affine_backward():
+    from dc_vic_amd.train import autograd as A
+    x, t, a = rnd(2, 16, 5, 7, seed=50), rnd(2, 16, 5, 7, seed=51), rnd(2, 16, 5, 7, seed=52)
+    rs = [v.clone().requires_grad_(True) for v in (x, t, a)]
+    y = rs[0] + rs[1] * torch.sigmoid(rs[2]); g = rnd(*y.shape, seed=53); y.backward(g)
+    ctx = A.Ctx([]); vs = [A.Var(v.to(DEV)) for v in (x, t, a)]
+    out = A.nlam_gate(ctx, *vs); out.grad = g.to(DEV); ctx.backward()
+    for v, r, nm in zip(vs, rs, "xta"):
+        relclose(v.grad, r.grad, 2e-5, f"nlam d{nm}")
+    rs = [v.clone().requires_grad_(True) for v in (x, t, a)]
+    y = rs[0] + 0.7 * (rs[0] * rs[1] + rs[2]); y.backward(g)
+    ctx = A.Ctx([]); vs = [A.Var(v.to(DEV)) for v in (x, t, a)]
+    out = A.sft(ctx, *vs, w=0.7); out.grad = g.to(DEV); ctx.backward()
+    for v, r, nm in zip(vs, rs, ("dec", "scale", "shift")):
+        relclose(v.grad, r.grad, 2e-5, f"sft d{nm}")
+    for B in (1, 2):      # shared and per-sample beta vectors; with and without the "+ x" of init_fuse
+        for add_x in (False, True):
+            s, sh = rnd(B, 16, 1, 1, seed=54), rnd(B, 16, 1, 1, seed=55)
+            xr, sr, tr = x.clone().requires_grad_(True), s.clone().requires_grad_(True), sh.clone().requires_grad_(True)
+            y = xr * (1 + sr) + tr + (xr if add_x else 0); y.backward(g)
+            ctx = A.Ctx([]); xv, sv, tv = A.Var(x.to(DEV)), A.Var(s.to(DEV)), A.Var(sh.to(DEV))
+            out = A.chan_affine(ctx, xv, sv, tv, add_x=add_x); out.grad = g.to(DEV); ctx.backward()
+            relclose(out.data, y, 1e-5, "chan_affine fwd"); relclose(xv.grad, xr.grad, 2e-5, "chan_affine dx")
+            relclose(sv.grad, sr.grad, 2e-5, "chan_affine ds"); relclose(tv.grad, tr.grad, 2e-5, "chan_affine dt")
+    # fan-out accumulation + channel concat
+    xr = x.clone().requires_grad_(True); tr = t.clone().requires_grad_(True)
+    y = torch.cat([xr, tr, xr], 1) * 1.0; y2 = y + F.interpolate(xr, scale_factor=2.0)[:, :, ::2, ::2].repeat(1, 3, 1, 1)
+    g3 = rnd(*y.shape, seed=56); y2.backward(g3)
+    ctx = A.Ctx([]); xv, tv = A.Var(x.to(DEV)), A.Var(t.to(DEV))
+    out = A.cat_channels(ctx, [xv, tv, xv]); out.grad = g3.to(DEV); ctx.backward()
+    relclose(xv.grad, g3[:, :16] + g3[:, 32:], 2e-5, "cat fan-out"); relclose(tv.grad, g3[:, 16:32], 2e-5, "cat middle")
+
+
+def test_attention_backward():
+    from dc_vic_amd.train import autograd as A
+    N, C, H, W = 2, 128, 8, 16
+    qkv = rnd(N, 3 * C, H, W, seed=60, scale=1.2)
+    r = qkv.clone().requires_grad_(True)
+    q, k, v = r[:, :C].flatten(2), r[:, C:2 * C].flatten(2), r[:, 2 * C:].flatten(2)
+    w_ = F.softmax(torch.bmm(q.permute(0, 2, 1), k) * C ** -0.5, dim=2)
+    o = torch.bmm(v, w_.permute(0, 2, 1)).view(N, C, H, W)
+    g = rnd(N, C, H, W, seed=61); o.backward(g)
+    ctx = A.Ctx([]); xv = A.Var(qkv.to(DEV)); out = A.attn_single_head(ctx, xv, C)
+    relclose(out.data, o, 2e-4, "attn fwd"); out.grad = g.to(DEV); ctx.backward()
+    relclose(xv.grad, r.grad, 2e-4, "attn dqkv")
+
+
+@pytest.mark.parametrize("shift", [0, 4])
+def test_swin_attention_backward(shift):
+    from dc_vic_amd.train import autograd as A
+    from oracle import dcvic_oracle as O
+    N, C, H, W, heads, ws = 2, 128, 16, 24, 8, 8
+    qkv, table = rnd(N, 3 * C, H, W, seed=62), 0.5 * rnd(225, heads, seed=63)
+    qr, tr = qkv.clone().requires_grad_(True), table.clone().requires_grad_(True)
+    t = qr.flatten(2).transpose(1, 2).view(N, H, W, 3 * C)
+    if shift:
+        t = torch.roll(t, shifts=(-shift, -shift), dims=(1, 2))
+    xw = t.view(N, H // ws, ws, W // ws, ws, 3 * C).permute(0, 1, 3, 2, 4, 5).reshape(-1, ws * ws, 3 * C)
+    B_, T, _ = xw.shape
+    qh = xw.reshape(B_, T, 3, heads, C // heads).permute(2, 0, 3, 1, 4)
+    att = (qh[0] * (C // heads) ** -0.5) @ qh[1].transpose(-2, -1)
+    att = att + tr[O._rel_pos_index(ws).view(-1)].view(T, T, -1).permute(2, 0, 1).unsqueeze(0)
+    if shift:
+        mask = O._shift_mask(H, W, ws, shift); nW = mask.shape[0]
+        att = (att.view(B_ // nW, nW, heads, T, T) + mask.unsqueeze(1).unsqueeze(0)).view(-1, heads, T, T)
+    xo = (F.softmax(att, dim=-1) @ qh[2]).transpose(1, 2).reshape(B_, T, C)
+    xo = xo.view(N, H // ws, W // ws, ws, ws, C).permute(0, 1, 3, 2, 4, 5).reshape(N, H, W, C)
+    if shift:
+        xo = torch.roll(xo, shifts=(shift, shift), dims=(1, 2))
+    o = xo.permute(0, 3, 1, 2)
+    g = rnd(N, C, H, W, seed=64); o.backward(g)
+    p = torch.nn.Parameter(table.to(DEV), requires_grad=False)
+    holder = torch.nn.Module(); holder.t = p
+    grp = A.ParamGroup([holder], DEV); ctx = A.Ctx([grp]); xv = A.Var(qkv.to(DEV))
+    out = A.swin_attention(ctx, xv, holder.t, heads, ws, shift)
+    relclose(out.data, o, 2e-5, "swin fwd"); out.grad = g.to(DEV); ctx.backward()
+    relclose(xv.grad, qr.grad, 5e-5, "swin dqkv"); relclose(grp.grad_of(holder.t), tr.grad, 5e-5, "swin dtable")
+
+
+def test_losses_and_adam():
+    from dc_vic_amd.train import autograd as A
+    from dc_vic_amd.train import kernels as K
+    a, b = rnd(2, 3, 16, 16, seed=70), rnd(2, 3, 16, 16, seed=71)
+    ar = a.clone().requires_grad_(True)
+    l = 50 * F.mse_loss((ar + 1) / 2, (b + 1) / 2); l.backward()
+    ctx = A.Ctx([]); av = A.Var(a.to(DEV)); v = A.mse_loss(ctx, av, b.to(DEV), 50 * 0.25)
+    relclose(v, l.reshape(1), 1e-6, "mse value"); relclose(av.grad, ar.grad, 1e-5, "mse grad")
+    x = rnd(2, 1, 30, 30, seed=72, scale=2.0)
+    for real in (True, False):
+        xr = x.clone().requires_grad_(True)
+        l = 0.5 * F.binary_cross_entropy_with_logits(xr, torch.full_like(xr, 1.0 if real else 0.0)); l.backward()
+        xv = A.Var(x.to(DEV)); v = A.bce_logits_loss(A.Ctx([]), xv, real, 0.5)
+        relclose(v, l.reshape(1), 1e-6, "bce value"); relclose(xv.grad, xr.grad, 1e-5, "bce grad")
+    lg, tg = rnd(2, 256, 8, 8, seed=73, scale=2.0), torch.randint(0, 256, (2, 8, 8), generator=torch.Generator().manual_seed(74))
+    lr_ = lg.clone().requires_grad_(True); l = 0.5 * F.cross_entropy(lr_, tg); l.backward()
+    lv = A.Var(lg.to(DEV)); v = A.cross_entropy_loss(A.Ctx([]), lv, tg.to(DEV), 0.5)
+    relclose(v, l.reshape(1), 1e-6, "ce value"); relclose(lv.grad, lr_.grad, 1e-5, "ce grad")
+    # Adam (3 steps, with the clip factor) vs torch.optim.Adam + clip_grad_norm_
+    p0 = rnd(1000, seed=75); pt = p0.clone().requires_grad_(True); opt = torch.optim.Adam([pt], lr=1e-3)
+    pd, m, vv = p0.to(DEV), torch.zeros(1000, device=DEV), torch.zeros(1000, device=DEV)
+    for step in range(1, 4):
+        gr = rnd(1000, seed=80 + step, scale=3.0)
+        pt.grad = gr.clone(); torch.nn.utils.clip_grad_norm_([pt], 1.0); opt.step()
+        gd = gr.to(DEV)
+        gs = K.clip_scale(K.reduce_loss(2, gd, None, 1.0), 1.0)
+        K.adam_step(pd, gd, m, vv, 1e-3, 0.9, 0.999, 1e-8, step, gs)
+        relclose(pd, pt.detach(), 2e-6, f"adam step {step}")
+
+
+# ------------------------------------------------------------------------------------------------ networks vs the oracle
+@pytest.fixture(scope="module")
+def model():
+    from dc_vic_amd import BaseConfig, build_comp_model
+    from dc_vic_amd.synth import load_synth_weights
+    opt = BaseConfig.fromfile(os.path.join(ROOT, "config", "dc_vic_synthetic.yaml"), {"device": DEV})
+    m = build_comp_model(opt)
+    load_synth_weights(m, 1234)
+    return m
+
+
+def _disc(seed=5):
+    from dc_vic_amd.train import DualBetaCondTamingNLayerDiscriminator
+    torch.manual_seed(seed)
+    D = DualBetaCondTamingNLayerDiscriminator(input_nc=11, n_layers=3, ndf=64, norm_type="none", max_beta_1=3.0, max_beta_2=3.5, L=10, cond_ch=8,
+                                              use_pi=False, include_x=True)
+    g = torch.Generator().manual_seed(seed)
+    for p in D.parameters():          # deterministic, a bit larger than N(0, 0.02) so the logits carry signal
+        p.data.copy_(torch.randn(p.shape, generator=g) * (0.05 if p.dim() > 1 else 0.02))
+    return D
+
+
+def test_generator_and_discriminator_step_vs_oracle(model, synth_sd):
+    """One full optimisation step of the stage-3 trainer on a seeded batch (2 x 64x64, per-sample beta pairs): every loss term,
+    every trainable parameter's gradient (decoder / vq_estimator / fusion_module: 33.5 M parameters), the clipped Adam update
+    and the D step, against torch autograd + torch.optim over the CPU oracle."""
+    from dc_vic_amd.train import DualBetaCondGanDistortionVqCodeTrainer
+    from dc_vic_amd.train import autograd as A
+    from oracle import train_oracle as T
+    from oracle.entropy_oracle import EntropyBottleneckOracle
+    D = _disc().to(DEV)
+    dsd0 = {k: v.detach().cpu().clone() for k, v in D.state_dict().items()}
+    tr = DualBetaCondGanDistortionVqCodeTrainer(model, D, lr_g=1e-4, lr_d=1e-4, clip_max_norm=1.0, seed=3)
+    x = torch.rand((2, 3, 64, 64), generator=torch.Generator().manual_seed(90)) * 2 - 1
+    b1, b2 = torch.tensor([2.29, 0.62]), torch.tensor([3.0, 1.5])
+    # ---- oracle
+    sd = {k: v.clone() for k, v in synth_sd.items()}
+    names = [k for k in sd if k.startswith(T.TRAINABLE_PREFIXES) and sd[k].is_floating_point()]
+    for k in names:
+        sd[k].requires_grad_(True)
+    dsd = {k: v.clone().requires_grad_(True) for k, v in dsd0.items()}
+    eb = EntropyBottleneckOracle(synth_sd, "entropy_model_z")
+    L, oo = T.generator_losses(sd, dsd, x, b1, b2, eb)
+    total = sum(L.values())
+    total.backward()
+    # ---- product: forward + losses + backward (no optimizer yet) for the gradient comparison
+    tr.g_group.zero_grad()
+    ctx = A.Ctx([tr.g_group])
+    o = tr.generator_forward(ctx, x, None, b1, b2)
+    assert torch.equal(o["gt_vq_indices"].cpu(), oo["gt_idx"]) and torch.equal(o["out_vq_indices"].cpu(), oo["out_idx"]), "integer decisions differ"
+    relclose(o["fake"].data, oo["fake"], 2e-4, "fake images")
+    glog = tr.calc_g_loss(ctx, o, b1, b2)
+    for k in ("distortion", "adv", "code_distortion", "code_ce"):
+        relclose(glog[k], L[k].detach().reshape(1), 2e-4, f"loss {k}")
+    ctx.backward()
+    own = dict(model.named_parameters())
+    worst = 0.0
+    checked = 0
+    for k in names:
+        gref = sd[k].grad
+        if gref is None:
+            continue                                     # e.g. decoder.conv4 (never executed) -> no gradient on either side
+        gp = tr.g_group.grad_of(own[k])
+        worst = max(worst, relclose(gp, gref, 3e-3, f"grad {k}"))
+        checked += 1
+    assert checked > 600, checked
+    unused = [k for k in names if sd[k].grad is None]
+    for k in unused:
+        assert float(tr.g_group.grad_of(own[k]).abs().max()) == 0.0, k
+    # ---- the real step (fresh gradients inside), then compare the updated parameters and the D step
+    new = T.clip_and_adam({k: synth_sd[k] for k in names if sd[k].grad is not None}, {k: sd[k].grad for k in names if sd[k].grad is not None}, 1e-4, 1.0)
+    log = tr.optimize_parameters(0, dict(real_images=x, beta_rate=b1, beta_vq=b2))
+    assert log is not None and abs(log["total"] - float(total)) < 2e-4 * abs(float(total))
+    for k in list(new)[::7]:
+        relclose(own[k].data - synth_sd[k].to(DEV), new[k] - synth_sd[k], 5e-2, f"adam update {k}")     # updates are ~lr-sized: compare the DELTA
+    l_real, l_fake, d_real, d_fake = T.discriminator_losses(dsd, x, oo["fake"], b1, b2)
+    for p in dsd.values():
+        p.grad = None
+    (l_real + l_fake).backward()
+    assert abs(log["d_real"] - float(l_real)) < 1e-4 and abs(log["d_fake"] - float(l_fake)) < 1e-4
+    newd = T.clip_and_adam(dsd0, {k: dsd[k].grad for k in dsd0}, 1e-4, None)
+    for k, p in D.state_dict().items():
+        relclose(p - dsd0[k].to(DEV), newd[k] - dsd0[k], 5e-2, f"D adam update {k}")
+    # restore the model's weights for other tests
+    from dc_vic_amd.synth import load_synth_weights
+    for p in model.parameters():
+        pass
