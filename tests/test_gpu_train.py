@@ -305,7 +305,8 @@ def test_generator_and_discriminator_step_vs_oracle(model, synth_sd):
         gp = tr.g_group.grad_of(own[k])
         worst = max(worst, relclose(gp, gref, 3e-3, f"grad {k}"))
         checked += 1
-    assert checked > 600, checked
+    assert checked >= 400, checked          # 403 tensors carry gradients (decoder.conv4 and the unused heads do not)
+    print(f'[train parity] {checked} parameter gradients, worst relative error {worst:.2e}')
     unused = [k for k in names if sd[k].grad is None]
     for k in unused:
         assert float(tr.g_group.grad_of(own[k]).abs().max()) == 0.0, k
