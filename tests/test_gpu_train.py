@@ -313,9 +313,20 @@ def test_generator_and_discriminator_step_vs_oracle(model, synth_sd):
     # ---- the real step (fresh gradients inside), then compare the updated parameters and the D step
     new = T.clip_and_adam({k: synth_sd[k] for k in names if sd[k].grad is not None}, {k: sd[k].grad for k in names if sd[k].grad is not None}, 1e-4, 1.0)
     log = tr.optimize_parameters(0, dict(real_images=x, beta_rate=b1, beta_vq=b2))
-    assert log is not None and abs(log["total"] - float(total)) < 2e-4 * abs(float(total))
-    for k in list(new)[::7]:
-        relclose(own[k].data - synth_sd[k].to(DEV), new[k] - synth_sd[k], 5e-2, f"adam update {k}")     # updates are ~lr-sized: compare the DELTA
+    assert log is not None and abs(log["total"] - float(total.detach())) < 2e-4 * abs(float(total.detach()))
+    gnorm = float(torch.sqrt(sum((sd[k].grad.double() ** 2).sum() for k in new)))
+    cscale = min(1.0, 1.0 / (gnorm + 1e-6))
+    n_cmp = 0
+    for k in list(new)[::5]:
+        # the first Adam step is -lr * g / (|g| + 1e-8): elements whose clipped gradient is not >> eps amplify any fp32
+        # difference in g, so the DELTA is compared where |g| >= 1e-6 (sign regime) and merely bounded by lr elsewhere
+        da, db = (own[k].data.cpu() - synth_sd[k]).double(), (new[k] - synth_sd[k]).double()
+        big = (sd[k].grad.abs() * cscale) >= 1e-6
+        assert float(da.abs().max()) <= 1e-4 * (1 + 1e-3)
+        if big.any():
+            assert float((da - db)[big].abs().max()) <= 2e-2 * 1e-4, k
+            n_cmp += int(big.sum())
+    assert n_cmp > 10000, n_cmp
     l_real, l_fake, d_real, d_fake = T.discriminator_losses(dsd, x, oo["fake"], b1, b2)
     for p in dsd.values():
         p.grad = None
@@ -323,7 +334,10 @@ def test_generator_and_discriminator_step_vs_oracle(model, synth_sd):
     assert abs(log["d_real"] - float(l_real)) < 1e-4 and abs(log["d_fake"] - float(l_fake)) < 1e-4
     newd = T.clip_and_adam(dsd0, {k: dsd[k].grad for k in dsd0}, 1e-4, None)
     for k, p in D.state_dict().items():
-        relclose(p - dsd0[k].to(DEV), newd[k] - dsd0[k], 5e-2, f"D adam update {k}")
+        da, db = (p.cpu() - dsd0[k]).double(), (newd[k] - dsd0[k]).double()
+        big = dsd[k].grad.abs() >= 1e-6
+        if big.any():
+            assert float((da - db)[big].abs().max()) <= 2e-2 * 1e-4, k
     # restore the model's weights for other tests
     from dc_vic_amd.synth import load_synth_weights
     for p in model.parameters():
