@@ -338,7 +338,40 @@ def test_generator_and_discriminator_step_vs_oracle(model, synth_sd):
         big = dsd[k].grad.abs() >= 1e-6
         if big.any():
             assert float((da - db)[big].abs().max()) <= 2e-2 * 1e-4, k
-    # restore the model's weights for other tests
-    from dc_vic_amd.synth import load_synth_weights
-    for p in model.parameters():
-        pass
+
+
+def test_training_steps_256_and_checkpoint(model, tmp_path):
+    """BASELINE config 5's sample shape (256x256 crops), per-sample beta pairs drawn by the trainer: a few G + D steps run, every
+    logged quantity is finite, the generator and discriminator weights move, the frozen sub-networks do not, the updated
+    decoder is what the inference path then uses, and the model state dict round-trips through the reference's checkpoint
+    format ({'iter', 'comp_model'}, model_saver.py:39-46)."""
+    from dc_vic_amd.train import DualBetaCondGanDistortionVqCodeTrainer
+    D = _disc(7).to(DEV)
+    tr = DualBetaCondGanDistortionVqCodeTrainer(model, D, seed=11)
+    frozen0 = model.vq_model.decoder.conv_in.weight.detach().clone()
+    enc0 = model.encoder.conv1.weight.detach().clone()
+    w0 = model.fusion_module.fusion_modules["block_1_8"].scale[2].weight.detach().clone()
+    d0 = D.main[0].weight.detach().clone()
+    x = torch.rand((2, 3, 256, 256), generator=torch.Generator().manual_seed(91)) * 2 - 1
+    logs = [tr.optimize_parameters(i, {"real_images": x}) for i in range(3)]
+    for lg in logs:
+        assert lg is not None and all(np.isfinite(v) for v in lg.values()), lg
+        assert 0.0 <= lg["vq_acc"] <= 1.0 and lg["qbpp"] > 0
+    assert torch.equal(model.vq_model.decoder.conv_in.weight, frozen0) and torch.equal(model.encoder.conv1.weight, enc0)
+    assert not torch.equal(model.fusion_module.fusion_modules["block_1_8"].scale[2].weight, w0) and not torch.equal(D.main[0].weight, d0)
+    assert logs[-1]["d_total"] < logs[0]["d_total"] + 1e-3            # D learns to separate real from fake on a fixed batch
+    # inference after training uses the updated weights (packed-weight caches were refreshed)
+    model.codec_setup()
+    r = model.compress(x[:1], 0)
+    img, _, yh = model.decompress(r["string_list"])
+    assert torch.equal(yh, r["y_hat"]) and img.shape == (1, 3, 256, 256)
+    path = str(tmp_path / "comp_model_iter0000003.pth.tar")
+    torch.save({"iter": 3, "comp_model": {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}}, path)
+    from dc_vic_amd import BaseConfig, build_comp_model
+    m2 = build_comp_model(BaseConfig.fromfile(os.path.join(ROOT, "config", "dc_vic_synthetic.yaml"), {"device": DEV}))
+    m2.load_learned_weight(path)
+    m2.codec_setup()
+    r2 = m2.compress(x[:1], 0)
+    assert r2["string_list"] == r["string_list"]
+    img2, _, _ = m2.decompress(r2["string_list"])
+    assert torch.equal(img2, img)

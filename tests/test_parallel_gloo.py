@@ -82,3 +82,37 @@ def test_rank_cpu_slices_cover_and_do_not_overlap():
         flat = [c for s_ in sl for c in s_]
         assert len(flat) == len(set(flat)) == 128 and all(len(s_) == 128 // lw for s_ in sl)
     assert rank_cpu_slice(5, 8, [0, 1]) == [1]        # more ranks than cores: wrap, never empty
+
+
+def _ar_worker(rank, world, port, out_dir):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from dc_vic_amd.train.trainer import allreduce_mean_
+    g = torch.Generator().manual_seed(rank)
+    flat = torch.randn(100003, generator=g)
+    nb = allreduce_mean_(flat, dist, bucket_bytes=64 * 1024)          # 7 buckets, the last one ragged
+    torch.save({"flat": flat, "buckets": nb}, os.path.join(out_dir, f"ar{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_bucketed_gradient_allreduce_world2(tmp_path):
+    """Data-parallel training: the flat gradient buffer is averaged over the ranks with bucketed
+    all-reduces; every rank ends with the same mean, whatever the bucket boundaries."""
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    mp.spawn(_ar_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    a, b = torch.load(tmp_path / "ar0.pt"), torch.load(tmp_path / "ar1.pt")
+    assert a["buckets"] == b["buckets"] == 7
+    assert torch.equal(a["flat"], b["flat"])
+    ref = 0.5 * (torch.randn(100003, generator=torch.Generator().manual_seed(0)) + torch.randn(100003, generator=torch.Generator().manual_seed(1)))
+    assert torch.allclose(a["flat"], ref, rtol=0, atol=1e-7)
+    from dc_vic_amd.train.trainer import MultiStepLR, allreduce_mean_
+    t = torch.ones(5)
+    assert allreduce_mean_(t, None) == 0 and torch.equal(t, torch.ones(5))         # single process: untouched
+    sch = MultiStepLR(1e-4, [3, 5], 0.1)
+    lrs = []
+    for _ in range(7):
+        lrs.append(sch.lr()); sch.step()
+    assert np.allclose(lrs, [1e-4] * 3 + [1e-5] * 2 + [1e-6] * 2)
