@@ -235,3 +235,31 @@ def test_calc_metrics_psnr_and_fid_patches(tmp_path):
     assert pt.shape == (2 * 3 + 1 * 2, 32, 32, 3)
     assert np.array_equal(pt[0], img[:32, :32]) and np.array_equal(pt[1], img[:32, 32:64])
     assert np.array_equal(pt[6], img[16:48, 16:48])
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/config"), reason="reference tree absent (GPU box)")
+@pytest.mark.parametrize("name", ["dc_vic_patchgan.yaml", "dc_vic_oasis.yaml", "exp1_stage3.yaml"])
+def test_reference_yamls_load_unchanged(name):
+    """README: the reference's YAMLs parse unchanged through BaseConfig (`_base_` chains, `_delete_`, CLI overrides): the two
+    shipped inference configs and the stage-3 training config (build container only)."""
+    from dc_vic_amd import BaseConfig
+    opt = BaseConfig.fromfile(os.path.join("/root/reference/config", name), {"device": "cpu", "quality": 2})
+    assert opt["model"]["type"] == "HyperpriorCharmDualCondVicModel"
+    sub = opt["subnet"]
+    assert sub["encoder"]["type"] == "ElicDualBetaFtVqScEncoder" and sub["decoder"]["type"] == "ElicDualBetaFtFeatFusionDecoder"
+    assert sub["context_model"]["type"] == "Minnen20CharmContextModel" and sub["context_model"]["max_support_slices"] == 4
+    assert sub["entropy_model_y"]["type"] == "SteGaussianMeanScaleConditional"
+    assert float(sub["decoder"]["max_beta_1"]) == 3.0 and float(sub["decoder"]["max_beta_2"]) == 3.5
+    assert list(opt["model"]["selected_beta_rate"]) == [2.29, 1.51, 1.12, 0.62, 0.16]
+    assert opt["device"] == "cpu" and opt["quality"] == 2
+    if name == "exp1_stage3.yaml":
+        assert opt["trainer"]["type"] == "DualBetaCondGanDistortionVqCodeTrainer" and opt["trainer"]["sample_beta_batch"] is True
+        assert opt["optim"]["g_scheduler"]["milestones"] == [300000] and opt["optim"]["clip_max_norm"] == 1.0
+        assert opt["loss"]["distortion_loss"]["loss_weight"] == 50 and opt["loss"]["code_ce_loss"]["loss_weight"] == 0.5
+        assert opt["discriminator"]["type"] == "DualBetaCondTamingNLayerDiscriminator" and opt["discriminator"]["input_nc"] == 11
+    # the model builds from the reference YAML (CPU instance: construction + state-dict layout only)
+    if name == "dc_vic_patchgan.yaml":
+        from dc_vic_amd import build_comp_model
+        opt["subnet"]["vq_model"]["ckpt_path"] = None
+        m = build_comp_model(opt)
+        assert "fusion_module.fusion_modules.block_1_2.fuse_block.conv1.weight" in m.state_dict()
