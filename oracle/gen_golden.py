@@ -216,6 +216,7 @@ def main():
         pe, lg = mods["vq_estimator"](ft)
         G[f"{tag}_feat"] = ft.numpy(); G[f"{tag}_argmax"] = lg.argmax(1).numpy()
         G[f"{tag}_logits_crop"] = lg[:, ::16, :4, :4].numpy(); G[f"{tag}_logits_sum"] = summ(lg)
+        G[f"{tag}_logits"] = lg.numpy()         # full logits: lets the GPU test itemise argmax near-ties by their margin
         G[f"{tag}_pred_embed"] = pe.numpy()
     # --- a16 + a17: LUT -> post_quant_conv -> fusion decoder
     idx3 = torch.randint(0, 256, (1, 8, 12), generator=torch.Generator().manual_seed(20))

@@ -22,21 +22,21 @@ from typing import Dict, List
 import numpy as np
 import torch
 
-# stage -> (rtol, atol).  Measured max-abs errors on MI355X are recorded next to each entry (report
-# "err" fields of the round-2 runs, 256x256 and 512x768, q 0..4); tolerance = ~10x the worst one.
+# stage -> (rtol, atol).  Tolerance = ~10x the largest max-abs error measured on MI355X over every case of the round-2 runs
+# (64x64 ... 512x768 Kodak images, q 0..4, tiling windows; gpurun_out/parity_report.json), quoted next to each entry.
 TOL = {
-    "z_e": (0.0, 1e-4),          # VQGAN encoder + quant_conv output (|z_e| ~ 0.02-0.05); measured <= 1.6e-6
-    "y": (0.0, 2e-4),            # ELIC encoder output (|y| up to ~3); measured <= 1.2e-5
-    "z": (0.0, 2e-4),            # hyper-encoder; measured <= 1.1e-5
-    "z_lik": (1e-4, 1e-9),       # EntropyBottleneck likelihood; measured rel <= 6e-6
-    "hyper_out": (0.0, 2e-4),    # hyper-decoder; measured <= 8e-6
-    "mu": (0.0, 2e-4),           # CHARM means; measured <= 1.3e-5
-    "sigma": (0.0, 2e-4),        # CHARM scales; measured <= 1.0e-5
-    "y_hat": (0.0, 2e-4),        # teacher-forced y_hat (symbols + mu + LRP); measured <= 1.3e-5
-    "y_lik": (2e-4, 1e-9),       # Gaussian likelihood given the oracle's (y_hat, mu, sigma); measured rel <= 3e-5
-    "feat": (0.0, 5e-4),         # ELIC decoder taps (|f| up to ~10); measured <= 4e-5
-    "logits": (0.0, 5e-4),       # Swin estimator logits (|l| up to ~6); measured <= 4e-5
-    "img": (0.0, 1e-3),          # reconstruction on [-1, 1] (1e-3); measured <= 6e-5
+    "z_e": (0.0, 5e-4),          # VQGAN encoder + quant_conv output (30 layers, |z_e| up to ~6); measured 5.0e-5
+    "y": (0.0, 3e-5),            # ELIC encoder output; measured 2.2e-6
+    "z": (0.0, 2e-5),            # hyper-encoder; measured 1.5e-6
+    "z_lik": (0.0, 2e-6),        # EntropyBottleneck likelihood (<= 1); measured 1.2e-7
+    "hyper_out": (0.0, 2e-5),    # hyper-decoder; measured 1.5e-6
+    "mu": (0.0, 3e-6),           # CHARM means; measured 1.4e-7
+    "sigma": (0.0, 1e-5),        # CHARM scales; measured 9.0e-7
+    "y_hat": (0.0, 5e-6),        # teacher-forced y_hat (symbols + mu + LRP); measured 2.4e-7
+    "y_lik": (0.0, 2e-6),        # Gaussian likelihood given the oracle's (y, mu, sigma); measured 1.2e-7
+    "feat": (0.0, 5e-5),         # ELIC decoder taps; measured 4.9e-6
+    "logits": (0.0, 1e-3),       # Swin estimator logits (|l| up to ~10); measured 1.0e-4
+    "img": (0.0, 4e-4),          # reconstruction on [-1, 1] (SURVEY 8d asks 1e-3); measured 3.8e-5
 }
 
 

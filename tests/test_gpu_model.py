@@ -1,4 +1,5 @@
-"""Stage-level and end-to-end parity of the HIP path on a real MI355X.
+"""Stage-level and end-to-end parity of the HIP path on a real MI355X.  Stage tolerances are absolute, ~10x the error
+measured on MI355X in round 2 (recorded per tag in gpurun_out/parity_report.json -> "stage_goldens").
 
  * stages vs the committed goldens (produced by the reference's own modules, oracle/gen_golden.py);
  * end-to-end vs the CPU oracle on the same seeded inputs, with integer decisions (VQ indices,
@@ -56,9 +57,9 @@ def img(shape, seed):
 # ------------------------------------------------------------------------------ stages vs goldens
 def test_stage_vqgan_encoder(model, golden):
     z = model.vq_model.encode(dev(golden["a4_x"]))
-    close(z, golden["a4_z"], rtol=2e-3, atol=2e-4, tag="a4_z")     # 30 layers of fp32 re-association
+    close(z, golden["a4_z"], rtol=0, atol=1.5e-4, tag="a4_z")     # 30 layers of fp32 re-association
     z = model.vq_model.encode(dev(golden["a4b_x"]))
-    close(z, golden["a4b_z"], rtol=2e-3, atol=2e-4, tag="a4b_z")
+    close(z, golden["a4b_z"], rtol=0, atol=1.5e-4, tag="a4b_z")
 
 
 def test_stage_vq_indices(model, golden):
@@ -77,32 +78,41 @@ def test_stage_elic_encoder(model, golden):
     _, _, feat = ops.vq_argmin(dev(golden["a4_z"]), model.vq_model.quantize.embedding.weight, want_zq=False, want_feat=True)
     for q in (0, 3):
         y = model.encoder(x, feat, model.selected_beta_rate[q], model.selected_beta_vq[q])
-        close(y, golden[f"a6_y_q{q}"], rtol=1e-3, atol=2e-4, tag="a6_y")
+        close(y, golden[f"a6_y_q{q}"], rtol=0, atol=2e-5, tag="a6_y")
     # per-sample beta tensors
     g = torch.Generator().manual_seed(15)
     f2 = (torch.randn((2, 260, 8, 8), generator=g) * 0.3).to("cuda:0")
     y = model.encoder(img((2, 3, 64, 64), 14).to("cuda:0"), f2, torch.tensor([2.29, 0.62]), torch.tensor([3.0, 1.5]))
-    close(y, golden["a6b_y"], rtol=1e-3, atol=2e-4, tag="a6b_y")
+    close(y, golden["a6b_y"], rtol=0, atol=2e-5, tag="a6b_y")
 
 
 def test_stage_hyper(model, golden):
-    close(model.hyperencoder(dev(golden["a6_y_q0"])), golden["a7_z"], rtol=1e-3, atol=1e-4, tag="a7_z")
-    close(model.hyperdecoder(dev(golden["a9_zhat"])), golden["a9_out"], rtol=1e-3, atol=1e-4, tag="a9_out")
+    close(model.hyperencoder(dev(golden["a6_y_q0"])), golden["a7_z"], rtol=0, atol=5e-6, tag="a7_z")
+    close(model.hyperdecoder(dev(golden["a9_zhat"])), golden["a9_out"], rtol=0, atol=6e-5, tag="a9_out")
 
 
 def test_stage_elic_decoder_feats(model, golden):
     f1, fd = model.decoder.get_feats(dev(golden["a14_yhat"]), model.selected_beta_rate[1], model.selected_beta_vq[1])
-    close(f1, golden["a14_feat1"], rtol=2e-3, atol=2e-3, tag="a14_feat1")
-    close(fd["block_1_4"][:, :, :8, :8], golden["a14_b14_crop"], rtol=2e-3, atol=2e-3, tag="a14_b14")
-    close(fd["block_1_2"][:, :, 10:18, 20:28], golden["a14_b12_crop"], rtol=2e-3, atol=2e-3, tag="a14_b12")
+    close(f1, golden["a14_feat1"], rtol=0, atol=4e-4, tag="a14_feat1")
+    close(fd["block_1_4"][:, :, :8, :8], golden["a14_b14_crop"], rtol=0, atol=4e-4, tag="a14_b14")
+    close(fd["block_1_2"][:, :, 10:18, 20:28], golden["a14_b12_crop"], rtol=0, atol=4e-4, tag="a14_b12")
 
 
 @pytest.mark.parametrize("tag", ["a15", "a15b"])
 def test_stage_swin_estimator(model, golden, tag):
     pe, lg = model.vq_estimator(dev(golden[f"{tag}_feat"]), want_embed=True)
-    close(pe, golden[f"{tag}_pred_embed"], rtol=2e-3, atol=2e-3, tag="a15_pred_embed")
-    close(lg[:, ::16, :4, :4], golden[f"{tag}_logits_crop"], rtol=5e-3, atol=5e-3, tag="a15_logits")
-    assert (lg.argmax(1).cpu().numpy() == golden[f"{tag}_argmax"]).mean() > 0.995
+    close(pe, golden[f"{tag}_pred_embed"], rtol=0, atol=1e-4, tag="a15_pred_embed")
+    close(lg[:, ::16, :4, :4], golden[f"{tag}_logits_crop"], rtol=0, atol=5e-4, tag="a15_logits")
+    # argmax decisions: exact, except where the reference's own top-2 margin is below the logit difference measured at that
+    # position (itemised near-ties)
+    from parity_util import Report, argmax_flips
+    rep = Report(f"stage_{tag}_argmax")
+    lo = torch.from_numpy(golden[f"{tag}_logits"])
+    assert np.array_equal(lo.argmax(1).numpy(), golden[f"{tag}_argmax"])
+    close(lg, lo, rtol=0, atol=5e-4, tag="a15_logits")
+    argmax_flips(rep, "argmax", lg.argmax(1), lg, lo)
+    rep.dump()
+    assert rep.n_flips() <= 2
 
 
 def test_stage_fusion_decoder(model, golden):
@@ -114,10 +124,10 @@ def test_stage_fusion_decoder(model, golden):
     close(lat, golden["a17_lat"], rtol=1e-5, atol=1e-7)
     cf = {k: dev(golden[f"a17_{k}"]) for k in ("block_1_8", "block_1_4", "block_1_2")}
     out = model.fusion_module(lat, cf, model.vq_model.decoder, w=1.0)
-    close(out[:, :, 16:48, 30:62], golden["a17_out_crop"], rtol=5e-3, atol=5e-3, tag="a17_out")
-    close(out[:, :, ::4, ::4], golden["a17_out_ds"], rtol=5e-3, atol=5e-3, tag="a17_out")
+    close(out[:, :, 16:48, 30:62], golden["a17_out_crop"], rtol=0, atol=2e-4, tag="a17_out")
+    close(out[:, :, ::4, ::4], golden["a17_out_ds"], rtol=0, atol=2e-4, tag="a17_out")
     plain = model.vq_model.decoder(lat)
-    close(plain[:, :, ::4, ::4], golden["a17p_out_ds"], rtol=5e-3, atol=5e-3, tag="a17p_out")
+    close(plain[:, :, ::4, ::4], golden["a17p_out_ds"], rtol=0, atol=1e-4, tag="a17p_out")
 
 
 # ------------------------------------------------------------------------------ a10 CHARM vs the reference module
@@ -135,9 +145,9 @@ def test_stage_charm_vs_reference_module(model, charm_golden, tag):
     sc = model.context_model.slice_ch
     r = model.context_model.run(None, ho, model.entropy_model_y, symbols_in=lambda i, ix: sym_ref[:, i * sc:(i + 1) * sc].contiguous(),
                                 want_likelihood=False)
-    close(r["mu"], G[f"{tag}_mu"], rtol=0, atol=1e-4, tag="charm_mu")
-    close(r["sigma"], G[f"{tag}_sigma"], rtol=0, atol=1e-4, tag="charm_sigma")
-    close(r["y_hat"], G[f"{tag}_y_hat"], rtol=0, atol=1e-4, tag="charm_y_hat")
+    close(r["mu"], G[f"{tag}_mu"], rtol=0, atol=1e-5, tag="charm_mu")
+    close(r["sigma"], G[f"{tag}_sigma"], rtol=0, atol=6e-5, tag="charm_sigma")
+    close(r["y_hat"], G[f"{tag}_y_hat"], rtol=0, atol=1e-5, tag="charm_y_hat")
     # free-running encode side: the HIP path rounds by itself
     rep = Report(f"charm_{tag}")
     f = model.context_model.run(y, ho, model.entropy_model_y, want_likelihood=True, want_symbols=True)
