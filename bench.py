@@ -210,14 +210,16 @@ def main():
             # HBM traffic per launch of that kernel: PMC counters need rocprofv3 (separate --pmc passes, see
             # tools/pmc_summary.py); the committed summary of the same command is reported when present
             traffic, traffic_src = None, None
-            try:
-                with open(os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")) as f:
-                    pm = json.load(f)
-                if k["kernel"] in pm:
-                    traffic = pm[k["kernel"]]["hbm_bytes_per_launch"]
-                    traffic_src = "profiles/r1_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of bench.py; 2*FETCH+WRITE, bytes per launch)"
-            except (OSError, ValueError):
-                pass
+            for pmf in ("r2_pmc_traffic.json", "r1_pmc_traffic.json"):
+                try:
+                    with open(os.path.join(ROOT, "profiles", pmf)) as f:
+                        pm = json.load(f)
+                    if k["kernel"] in pm:
+                        traffic = pm[k["kernel"]]["hbm_bytes_per_launch"]
+                        traffic_src = f"profiles/{pmf} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of bench.py; 2*FETCH+WRITE, bytes per launch)"
+                        break
+                except (OSError, ValueError):
+                    pass
             out["roofline"] = {"bound": "mfma", "kernel": k["kernel"], "achieved": k["flops"] / k["time_s"] / 1e12,
                                "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": k["flops"] / k["time_s"] / 1e12 / PEAK_F32_MFMA_TFLOPS,
                                "traffic": traffic, "traffic_source": traffic_src, "launches": k["launches"], "avg_launch_us": 1e6 * k["time_s"] / k["launches"],
