@@ -6,7 +6,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libdcvic_hip.so")
+LIB_PATH = os.environ.get("DCVIC_LIB_PATH") or os.path.join(_HERE, "libdcvic_hip.so")   # DCVIC_LIB_PATH: diagnostic builds (tools/)
 
 MAX_TAPS = 25
 MAX_SRC = 3

@@ -24,6 +24,16 @@ typedef __attribute__((address_space(3))) void* lds_ptr_t;
 
 __device__ float dcvic_zero_word[16];   // zero-initialised: source of padded lanes
 
+// Diagnostic build only (-DDCVIC_STAMPS, tools/build_stamps.sh; never in libdcvic_hip.so): per-wave cycle sums of the three
+// phases of a pipeline stage (DMA issue / MFMA loop / barrier), prologue and epilogue, written to a buffer of their own.
+#ifdef DCVIC_STAMPS
+__device__ unsigned long long* dcvic_stamp_buf;
+extern "C" int dcvic_debug_set_stamp_buffer(unsigned long long* p) {
+    return hipMemcpyToSymbol(HIP_SYMBOL(dcvic_stamp_buf), &p, sizeof(p)) == hipSuccess ? 0 : -1;
+}
+#define DCVIC_STAMP() __builtin_amdgcn_s_memtime()
+#endif
+
 #define D_TW 32
 #define D_TH 8
 #define D_THREADS 512
@@ -120,17 +130,26 @@ __global__ __launch_bounds__(D_THREADS, 4) void conv3x3_dma_kernel(const ConvKAr
     }
     int w_sub = 0;                                               // 4-channel sub-stage inside the chunk of the NEXT stage
 
-    auto issue = [&](int stage, int buf) {
+    // One DMA piece of the NEXT stage: pieces [0, D_SLOTS) are patch slots, [D_SLOTS, D_SLOTS + NWJ) weight rows.  The pieces are
+    // issued from INSIDE the MFMA loop of the current stage, one every other step: measured with in-kernel stamps
+    // (tools/conv_stamps.py), a separate issue phase at the top of a stage took 4.8k of a wave's 17.8k cycles per stage -- each of
+    // its ~75 instructions waits for an issue slot between the other waves' MFMAs -- and because the waves of a workgroup are
+    // barrier-synchronised both co-resident workgroups regularly sat in their issue / barrier phases together: 14 % of the
+    // matrix-pipe cycles idle.  Interleaved, a wave never stops issuing MFMAs for more than one instruction.
+    constexpr int NPIECE = D_SLOTS + NWJ;
+    auto issue_piece = [&](auto p_, int buf) {
+        constexpr int p = decltype(p_)::value;
         float* xb = smem + buf * D_BUF;
         float* wb = xb + D_XS;
-#pragma unroll
-        for (int s = 0; s < D_SLOTS; ++s)
-            __builtin_amdgcn_global_load_lds(xp[s], (lds_ptr_t)(xb + wave * 64 + s * D_THREADS), 4, 0, 0);
-#pragma unroll
-        for (int j = 0; j < NWJ; ++j)
+        if constexpr (p < D_SLOTS) {
+            __builtin_amdgcn_global_load_lds(xp[p], (lds_ptr_t)(xb + wave * 64 + p * D_THREADS), 4, 0, 0);
+        } else {
+            constexpr int j = p - D_SLOTS;
             if (j * D_THREADS + tid < NV)                         // whole waves for TCV = 128; the last wave is partial for 96
                 __builtin_amdgcn_global_load_lds(reinterpret_cast<const float4*>(wp4[j]), (lds_ptr_t)(wb + (wave * 64 + j * D_THREADS) * 4), 16, 0, 0);
-        // advance to the next stage
+        }
+    };
+    auto advance = [&](int stage) {                               // pointers of the stage after `stage`
         x_left -= D_SKC;
         if (x_left > 0) {
 #pragma unroll
@@ -143,6 +162,10 @@ __global__ __launch_bounds__(D_THREADS, 4) void conv3x3_dma_kernel(const ConvKAr
 #pragma unroll
         for (int j = 0; j < NWJ; ++j) wp4[j] += wstep;
     };
+    auto issue = [&](int stage, int buf) {                        // prologue form: all pieces at once
+        dcvic_static_for<0, NPIECE>([&](auto p_) { issue_piece(p_, buf); });
+        advance(stage);
+    };
 
     // the workgroup's bias values go to LDS (read in the epilogue without touching vmcnt)
     float* const sbias = smem + 2 * D_BUF;
@@ -152,9 +175,20 @@ __global__ __launch_bounds__(D_THREADS, 4) void conv3x3_dma_kernel(const ConvKAr
 
     const int xlane = lane_k * D_PLANE + (wn * NT) * D_PW + lane_j;
     const int alane = lane_k * D_TC + wm * (MT * 32) + lane_j;
+#ifdef DCVIC_STAMPS
+    unsigned long long st_issue = 0, st_mfma = 0, st_bar = 0;
+    const unsigned long long st_loop0 = DCVIC_STAMP();
+#endif
     for (int stage = 0; stage < n_stages; ++stage) {
         const int buf = stage & 1;
-        if (stage + 1 < n_stages) issue(stage + 1, buf ^ 1);
+#ifdef DCVIC_STAMPS
+        const unsigned long long st_a = DCVIC_STAMP();
+#endif
+        const bool more = stage + 1 < n_stages;
+#ifdef DCVIC_STAMPS
+        const unsigned long long st_b = DCVIC_STAMP();
+        st_issue += st_b - st_a;
+#endif
         const float* xb = smem + buf * D_BUF + xlane;
         const float* wb = smem + buf * D_BUF + D_XS + alane;
         // T x SKC/2 steps (taps x channel pairs), software pipelined: the fragments of step s+1 are in flight
@@ -164,8 +198,13 @@ __global__ __launch_bounds__(D_THREADS, 4) void conv3x3_dma_kernel(const ConvKAr
         for (int mt = 0; mt < MT; ++mt) a_cur[mt] = wb[mt * 32];
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) b_cur[nt] = xb[nt * D_PW];
-#pragma unroll
-        for (int step = 0; step < T * D_SKC / 2; ++step) {
+        constexpr int NSTEP = T * D_SKC / 2;
+        static_assert(2 * NPIECE <= NSTEP, "one DMA piece every other MFMA step must fit the stage");
+        dcvic_static_for<0, NSTEP>([&](auto step_) {
+            constexpr int step = decltype(step_)::value;
+            if constexpr ((step & 1) == 1 && step / 2 < NPIECE) {
+                if (more) issue_piece(std::integral_constant<int, step / 2>{}, buf ^ 1);
+            }
             if (step + 1 < T * D_SKC / 2) {
                 const int t = (step + 1) / (D_SKC / 2), ks = (step + 1) % (D_SKC / 2);
                 const int ky = t / TX, kx = t - TX * ky;
@@ -185,9 +224,27 @@ __global__ __launch_bounds__(D_THREADS, 4) void conv3x3_dma_kernel(const ConvKAr
             for (int i = 0; i < MT; ++i) a_cur[i] = a_nxt[i];
 #pragma unroll
             for (int i = 0; i < NT; ++i) b_cur[i] = b_nxt[i];
-        }
+        });
+        if (more) advance(stage + 1);
+#ifdef DCVIC_STAMPS
+        const unsigned long long st_c = DCVIC_STAMP();
+        st_mfma += st_c - st_b;
+#endif
         if (stage + 1 < n_stages) __syncthreads();             // nothing reads the staging buffers after the last stage
+#ifdef DCVIC_STAMPS
+        st_bar += DCVIC_STAMP() - st_c;
+#endif
     }
+#ifdef DCVIC_STAMPS
+    {
+        const unsigned long long st_e = DCVIC_STAMP();
+        if (dcvic_stamp_buf && lane == 0) {
+            unsigned long long* o = dcvic_stamp_buf + ((long long)blockIdx.x * 8 + wave) * 8;
+            o[0] = st_issue; o[1] = st_mfma; o[2] = st_bar; o[3] = st_loop0; o[4] = st_e; o[5] = (unsigned long long)n_stages;
+            o[6] = __builtin_amdgcn_s_getreg(6 | (8 << 6) | (3 << 11));   // HW_ID bits [11:8] = cu_id
+        }
+    }
+#endif
 
     // ---- epilogue: bias -> act -> (+res) -> (affine) -> store  (same order as conv.hip)
     const long long HWo = (long long)K.Hfull * K.Wfull;
