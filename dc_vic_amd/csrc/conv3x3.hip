@@ -37,6 +37,9 @@ extern "C" int dcvic_debug_set_stamp_buffer(unsigned long long* p) {
 #define D_TW 32
 #define D_TH 8
 #define D_THREADS 512
+#ifndef DCVIC_CONV_STAGGER
+#define DCVIC_CONV_STAGGER 1      // 0: the round-1 schedule (two buffers, all eight waves in step); kept for A/B runs
+#endif
 
 // TCV = 128: waves 2 (channel halves) x 4 (row pairs), each 64 ch x 2 rows (MT = NT = 2);
 // TCV =  96: waves 1 x 8 (rows), each 96 ch x 1 row (MT = 3, NT = 1) -- the ELIC 96 / 192-channel layers
@@ -56,6 +59,9 @@ __global__ __launch_bounds__(D_THREADS, 4) void conv3x3_dma_kernel(const ConvKAr
     constexpr int D_CHUNK_W = T * KC * D_TC;                    // floats of one packed 8-channel chunk
     constexpr int NV = T * D_SKC * (D_TC / 4);                  // float4 of weights per stage
     extern __shared__ __attribute__((aligned(16))) float smem[];
+#ifdef DCVIC_STAMPS
+    const unsigned long long st_entry = DCVIC_STAMP();
+#endif
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // 0..7, an SGPR: LDS-DMA destinations stay scalar
@@ -167,14 +173,106 @@ __global__ __launch_bounds__(D_THREADS, 4) void conv3x3_dma_kernel(const ConvKAr
         advance(stage);
     };
 
+    const int xlane = lane_k * D_PLANE + (wn * NT) * D_PW + lane_j;
+    const int alane = lane_k * D_TC + wm * (MT * 32) + lane_j;
+    constexpr int NSTEP = T * D_SKC / 2;
+#if DCVIC_CONV_STAGGER
+    // ---- staggered schedule: THREE staging buffers, waves 4..7 run HALF A STAGE behind waves 0..3.
+    // Waves w and w + 4 share a SIMD and run the same program with one barrier per stage: in lockstep both reach the barrier,
+    // the post-barrier operand reads and the DMA issue together and leave the SIMD's matrix pipe to the other workgroup alone
+    // (MI355X_MICROARCH "two waves per SIMD", item 9).  Half-periods h = 0 .. 2 n: the leading group runs (stage, half) =
+    // (h >> 1, h & 1), the trailing group the same one half-period later; everybody meets at ONE barrier per period (even h).
+    // In every odd half-period each wave issues its DMA pieces of stage (h + 1) / 2 into ring[stage % 3], whose previous
+    // occupant (stage - 3) was last read two barriers ago; the barrier at h = 2 i then makes stage i complete for both groups.
+    // Per-wave arithmetic is unchanged (same MFMA sequence), so results stay bit-identical.
+    constexpr int HS = NSTEP / 2;
+    static_assert(NSTEP % 2 == 0 && NPIECE <= HS, "half a stage must hold the DMA pieces");
+    float* const sbias = smem + 3 * D_BUF;
+    if (tid < D_TC) sbias[tid] = K.bias ? K.bias[min(cotile * D_TC + tid, K.Cout - 1)] : 0.f;
+    issue(0, 0);
+    const int grp = wave >> 2;
+    auto run_half = [&](auto part_, auto issue_, int stage) {
+        constexpr int part = decltype(part_)::value;
+        constexpr bool do_issue = decltype(issue_)::value;
+        const int buf = stage % 3, nbuf = (stage + 1) % 3;
+        const bool more = stage + 1 < n_stages;
+        const float* xb = smem + buf * D_BUF + xlane;
+        const float* wb = smem + buf * D_BUF + D_XS + alane;
+        float a_cur[MT], b_cur[NT], a_nxt[MT], b_nxt[NT];
+        {
+            constexpr int s0 = part * HS, t = s0 / (D_SKC / 2), ks = s0 % (D_SKC / 2), ky = t / TX, kx = t - TX * ky;
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) a_cur[mt] = wb[(t * D_SKC + 2 * ks) * D_TC + mt * 32];
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) b_cur[nt] = xb[(2 * ks) * D_PLANE + (nt + ky) * D_PW + kx];
+        }
+        dcvic_static_for<0, HS>([&](auto i_) {
+            constexpr int i = decltype(i_)::value, step = part * HS + i;
+            if constexpr (do_issue && i < NPIECE) {
+                if (more) issue_piece(std::integral_constant<int, i>{}, nbuf);
+            }
+            if constexpr (i + 1 < HS) {
+                constexpr int t = (step + 1) / (D_SKC / 2), ks = (step + 1) % (D_SKC / 2), ky = t / TX, kx = t - TX * ky;
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) a_nxt[mt] = wb[(t * D_SKC + 2 * ks) * D_TC + mt * 32];
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) b_nxt[nt] = xb[(2 * ks) * D_PLANE + (nt + ky) * D_PW + kx];
+            }
+            __builtin_amdgcn_sched_barrier(0);   // keep the prefetch of step s+1 ahead of the MFMAs of step s
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[mt], b_cur[nt], acc[mt][nt], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int k = 0; k < MT; ++k) a_cur[k] = a_nxt[k];
+#pragma unroll
+            for (int k = 0; k < NT; ++k) b_cur[k] = b_nxt[k];
+        });
+        if (do_issue && more) advance(stage + 1);
+    };
+    using P0 = std::integral_constant<int, 0>;
+    using P1 = std::integral_constant<int, 1>;
+#ifdef DCVIC_STAMPS
+    const unsigned long long st_loop0 = DCVIC_STAMP();
+#endif
+    // one straight-line loop per group (a single loop with per-half branches made hipcc shuffle the 64 accumulators through
+    // scratch at every branch): n + 1 barriers on both sides
+    if (grp == 0) {
+        for (int stage = 0; stage < n_stages; ++stage) {
+            __syncthreads();                                   // stage `stage` has landed; everyone is past stage - 2
+            run_half(P0{}, std::false_type{}, stage);
+            run_half(P1{}, std::true_type{}, stage);           // + DMA pieces of stage + 1
+        }
+        __syncthreads();
+    } else {
+        __syncthreads();
+        for (int stage = 0; stage < n_stages; ++stage) {
+            run_half(P0{}, std::true_type{}, stage);           // + DMA pieces of stage + 1
+            __syncthreads();                                   // (the leading group is entering stage + 1)
+            run_half(P1{}, std::false_type{}, stage);
+        }
+    }
+#ifdef DCVIC_STAMPS
+    const unsigned long long st_loop1 = DCVIC_STAMP();
+#define DCVIC_STAMP_END()                                                                                             \
+    if (dcvic_stamp_buf && lane == 0) {                                                                               \
+        unsigned long long* o_ = dcvic_stamp_buf + ((long long)blockIdx.x * 8 + wave) * 8;                            \
+        o_[0] = st_entry; o_[1] = st_loop0; o_[2] = st_loop1; o_[3] = DCVIC_STAMP();                                  \
+        o_[4] = __builtin_amdgcn_s_getreg(4 | (0 << 6) | (31 << 11)); o_[5] = __builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)); \
+        o_[6] = (unsigned long long)n_stages;                                                                          \
+    }
+#else
+#define DCVIC_STAMP_END()
+#endif
+#else
     // the workgroup's bias values go to LDS (read in the epilogue without touching vmcnt)
     float* const sbias = smem + 2 * D_BUF;
     if (tid < D_TC) sbias[tid] = K.bias ? K.bias[min(cotile * D_TC + tid, K.Cout - 1)] : 0.f;
     issue(0, 0);
     __syncthreads();
 
-    const int xlane = lane_k * D_PLANE + (wn * NT) * D_PW + lane_j;
-    const int alane = lane_k * D_TC + wm * (MT * 32) + lane_j;
 #ifdef DCVIC_STAMPS
     unsigned long long st_issue = 0, st_mfma = 0, st_bar = 0;
     const unsigned long long st_loop0 = DCVIC_STAMP();
@@ -198,7 +296,6 @@ __global__ __launch_bounds__(D_THREADS, 4) void conv3x3_dma_kernel(const ConvKAr
         for (int mt = 0; mt < MT; ++mt) a_cur[mt] = wb[mt * 32];
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) b_cur[nt] = xb[nt * D_PW];
-        constexpr int NSTEP = T * D_SKC / 2;
         static_assert(2 * NPIECE <= NSTEP, "one DMA piece every other MFMA step must fit the stage");
         dcvic_static_for<0, NSTEP>([&](auto step_) {
             constexpr int step = decltype(step_)::value;
@@ -235,17 +332,11 @@ __global__ __launch_bounds__(D_THREADS, 4) void conv3x3_dma_kernel(const ConvKAr
         st_bar += DCVIC_STAMP() - st_c;
 #endif
     }
-#ifdef DCVIC_STAMPS
-    {
-        const unsigned long long st_e = DCVIC_STAMP();
-        if (dcvic_stamp_buf && lane == 0) {
-            unsigned long long* o = dcvic_stamp_buf + ((long long)blockIdx.x * 8 + wave) * 8;
-            o[0] = st_issue; o[1] = st_mfma; o[2] = st_bar; o[3] = st_loop0; o[4] = st_e; o[5] = (unsigned long long)n_stages;
-            o[6] = __builtin_amdgcn_s_getreg(6 | (8 << 6) | (3 << 11));   // HW_ID bits [11:8] = cu_id
-        }
-    }
-#endif
 
+#endif
+#ifndef DCVIC_STAMP_END
+#define DCVIC_STAMP_END()
+#endif
     // ---- epilogue: bias -> act -> (+res) -> (affine) -> store  (same order as conv.hip)
     const long long HWo = (long long)K.Hfull * K.Wfull;
     // Fast form for interior tiles without the affine: the residuals of the next 8-value sub-group are requested BEFORE
@@ -298,6 +389,7 @@ __global__ __launch_bounds__(D_THREADS, 4) void conv3x3_dma_kernel(const ConvKAr
                 *reinterpret_cast<float*>(ob + (goff[g] + (unsigned)((r & 3) + 8 * (r >> 2)) * rstep)) = v[r - r0];
             });
         });
+        DCVIC_STAMP_END()
         return;
     }
     dcvic_epilogue_dispatch(K, [&](auto res_, auto aff_) {
@@ -315,6 +407,7 @@ __global__ __launch_bounds__(D_THREADS, 4) void conv3x3_dma_kernel(const ConvKAr
             }
         });
     });
+    DCVIC_STAMP_END()
 }
 
 template <int TY, int TX, int SKC, int TCV>
@@ -323,7 +416,7 @@ static int launch_tap_dma(const ConvKArgs& A, hipStream_t st) {
     auto k = conv3x3_dma_kernel<TY, TX, SKC, TCV>;
     constexpr int PLANE = (D_TH + TY - 1) * (D_TW + TX - 1);
     constexpr int XS = ((SKC * PLANE + D_THREADS - 1) / D_THREADS) * D_THREADS;
-    const size_t lds = (size_t)(2 * (XS + TY * TX * SKC * TCV) + TCV) * sizeof(float);   // + the bias row
+    const size_t lds = (size_t)((DCVIC_CONV_STAGGER ? 3 : 2) * (XS + TY * TX * SKC * TCV) + TCV) * sizeof(float);   // + the bias row
     if (dcvic_first_use_on_device(attr_mask)) {
         hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     }
