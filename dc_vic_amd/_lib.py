@@ -66,7 +66,7 @@ SYMBOLS = [
     "dcvic_conv_wgrad_workspace_floats", "dcvic_conv_wgrad_f32", "dcvic_chan_reduce_f32", "dcvic_sum_rows_f32", "dcvic_ew_bwd_f32",
     "dcvic_groupnorm_bwd_f32", "dcvic_layernorm_c_bwd_blocks", "dcvic_layernorm_c_bwd_f32", "dcvic_softmax_c_bwd_f32",
     "dcvic_swin_attn_bwd_f32", "dcvic_reduce_loss_f32", "dcvic_cross_entropy_f32", "dcvic_adam_step_f32", "dcvic_clip_scale_f32",
-    "dcvic_resample2_f32",
+    "dcvic_resample2_f32", "dcvic_s2d_f32", "dcvic_maxpool3s2_f32", "dcvic_lpips_tap_f32",
 ]
 
 _lib = None

@@ -636,3 +636,120 @@ extern "C" int dcvic_resample2_f32(int down, const float* in, float* out, long l
     DCVIC_CHECK_LAUNCH("resample2");
     return DCVIC_OK;
 }
+
+// ------------------------------------------------------------------------------------------------ LPIPS pieces
+// (src/losses/perceptual_loss.py:10-30 -> lpips.LPIPS(net='alex'): AlexNet features, channel-normalise, squared difference,
+//  learned non-negative 1x1 heads, spatial mean, sum over the 5 taps.  The package and its weights are not in the reference
+//  tree: restated from the published architecture, parity unpinned.)
+// space-to-depth with zero padding: in [P planes][H][W] -> out [P][r*r][Ho][Wo], out[p][dy*r+dx][y][x] = in[p][y*r+dy-pad][x*r+dx-pad];
+// inverse = 1 is the adjoint (depth-to-space + crop).  The 11x11 / stride-4 / pad-2 stem of AlexNet becomes a 3x3 / stride-1
+// convolution over 48 channels this way (kernel zero-padded to 12x12).
+__global__ __launch_bounds__(256) void s2d_kernel(const float* __restrict__ in, float* __restrict__ out, long long planes, int H, int W,
+                                                  int r, int pad, int Ho, int Wo, int inverse) {
+    if (!inverse) {
+        const long long total = planes * r * r * Ho * Wo;
+        const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+        if (i >= total) return;
+        const int x = (int)(i % Wo); long long t = i / Wo;
+        const int y = (int)(t % Ho); t /= Ho;
+        const int d = (int)(t % (r * r)); const long long p = t / (r * r);
+        const int iy = y * r + d / r - pad, ix = x * r + d % r - pad;
+        out[i] = (iy >= 0 && iy < H && ix >= 0 && ix < W) ? in[(p * H + iy) * W + ix] : 0.f;
+    } else {          // `in` is the depth tensor [P][r*r][Ho][Wo], `out` the image-side gradient [P][H][W]
+        const long long total = planes * H * W;
+        const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+        if (i >= total) return;
+        const int ix = (int)(i % W); long long t = i / W;
+        const int iy = (int)(t % H); const long long p = t / H;
+        const int yy = iy + pad, xx = ix + pad;
+        const int y = yy / r, x = xx / r, d = (yy % r) * r + xx % r;
+        out[i] = (y < Ho && x < Wo) ? in[((p * r * r + d) * Ho + y) * Wo + x] : 0.f;
+    }
+}
+extern "C" int dcvic_s2d_f32(const float* in, float* out, long long planes, int H, int W, int r, int pad, int inverse, void* stream) {
+    DCVIC_CHECK_ARG(in && out && planes > 0 && r >= 1, "s2d: bad argument");
+    const int Ho = (H + 2 * pad) / r, Wo = (W + 2 * pad) / r;
+    const long long total = inverse ? planes * H * W : planes * r * r * Ho * Wo;
+    s2d_kernel<<<dcvic_cdiv(total, 256), 256, 0, (hipStream_t)stream>>>(in, out, planes, H, W, r, pad, Ho, Wo, inverse);
+    DCVIC_CHECK_LAUNCH("s2d");
+    return DCVIC_OK;
+}
+// MaxPool2d(3, stride 2), floor mode.  fwd: out + argmax position (0..8, first maximum); bwd (gather form, deterministic):
+// dx[i] = sum over the <= 4 windows that contain i of dy[window] if that window's argmax is i.
+__global__ __launch_bounds__(256) void maxpool3s2_kernel(const float* __restrict__ x, float* __restrict__ y, unsigned char* __restrict__ am,
+                                                         long long planes, int H, int W, int Ho, int Wo) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= planes * Ho * Wo) return;
+    const int ox = (int)(i % Wo); long long t = i / Wo;
+    const int oy = (int)(t % Ho); const long long p = t / Ho;
+    const float* xp = x + p * H * W + (long long)(2 * oy) * W + 2 * ox;
+    float best = xp[0]; int bi = 0;
+#pragma unroll
+    for (int k = 1; k < 9; ++k) { const float v = xp[(k / 3) * W + k % 3]; if (v > best) { best = v; bi = k; } }
+    y[i] = best; am[i] = (unsigned char)bi;
+}
+__global__ __launch_bounds__(256) void maxpool3s2_bwd_kernel(const float* __restrict__ dy, const unsigned char* __restrict__ am, float* __restrict__ dx,
+                                                             long long planes, int H, int W, int Ho, int Wo) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= planes * H * W) return;
+    const int ix = (int)(i % W); long long t = i / W;
+    const int iy = (int)(t % H); const long long p = t / H;
+    float s = 0.f;
+    for (int oy = max(0, (iy - 1) / 2); oy <= min(Ho - 1, iy / 2); ++oy)
+        for (int ox = max(0, (ix - 1) / 2); ox <= min(Wo - 1, ix / 2); ++ox) {
+            const int ky = iy - 2 * oy, kx = ix - 2 * ox;
+            if (ky >= 0 && ky < 3 && kx >= 0 && kx < 3 && am[(p * Ho + oy) * Wo + ox] == ky * 3 + kx) s += dy[(p * Ho + oy) * Wo + ox];
+        }
+    dx[i] = s;
+}
+extern "C" int dcvic_maxpool3s2_f32(const float* x, float* y, unsigned char* argmax, const float* dy, float* dx, long long planes, int H, int W,
+                                    void* stream) {
+    DCVIC_CHECK_ARG(argmax && planes > 0 && H >= 3 && W >= 3, "maxpool: bad argument");
+    const int Ho = (H - 3) / 2 + 1, Wo = (W - 3) / 2 + 1;
+    if (dx) {
+        DCVIC_CHECK_ARG(dy, "maxpool bwd: null dy");
+        maxpool3s2_bwd_kernel<<<dcvic_cdiv(planes * H * W, 256), 256, 0, (hipStream_t)stream>>>(dy, argmax, dx, planes, H, W, Ho, Wo);
+    } else {
+        DCVIC_CHECK_ARG(x && y, "maxpool fwd: null pointer");
+        maxpool3s2_kernel<<<dcvic_cdiv(planes * Ho * Wo, 256), 256, 0, (hipStream_t)stream>>>(x, y, argmax, planes, H, W, Ho, Wo);
+    }
+    DCVIC_CHECK_LAUNCH("maxpool3s2");
+    return DCVIC_OK;
+}
+// One LPIPS tap: u = f / (||f||_c + 1e-10) per pixel for both feature maps, val[n] = (1/HW) sum_p sum_c w[c] (u0 - u1)^2  (per-pixel
+// values in pix[n][p], reduced by dcvic_reduce_loss_f32 kind 3), and -- if df1 -- the gradient of (gscale * val) w.r.t. f1.
+__global__ __launch_bounds__(256) void lpips_tap_kernel(const float* __restrict__ f0, const float* __restrict__ f1, const float* __restrict__ w,
+                                                        float* __restrict__ pix, float* __restrict__ df1, int C, int HW, float gscale) {
+    const int n = blockIdx.y, p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= HW) return;
+    const float* a = f0 + (long long)n * C * HW + p;
+    const float* b = f1 + (long long)n * C * HW + p;
+    float s0 = 0.f, s1 = 0.f;
+    for (int c = 0; c < C; ++c) { const float x = a[(long long)c * HW], y = b[(long long)c * HW]; s0 += x * x; s1 += y * y; }
+    const float r1 = sqrtf(s1), n0 = sqrtf(s0) + 1e-10f, n1 = r1 + 1e-10f;
+    float val = 0.f, dot = 0.f;
+    for (int c = 0; c < C; ++c) {
+        const float d = a[(long long)c * HW] / n0 - b[(long long)c * HW] / n1;
+        val += w[c] * d * d;
+        dot += (-2.f * w[c] * d) * b[(long long)c * HW];          // sum_c a_c f1_c with a_c = dval/du1_c
+    }
+    pix[(long long)n * HW + p] = val;
+    if (df1) {
+        const float g = gscale / (float)HW;
+        const float k2 = r1 > 0.f ? dot / (r1 * n1 * n1) : 0.f;
+        float* o = df1 + (long long)n * C * HW + p;
+        for (int c = 0; c < C; ++c) {
+            const float y = b[(long long)c * HW];
+            const float ac = -2.f * w[c] * (a[(long long)c * HW] / n0 - y / n1);
+            o[(long long)c * HW] = g * (ac / n1 - y * k2);
+        }
+    }
+}
+extern "C" int dcvic_lpips_tap_f32(const float* f0, const float* f1, const float* w, float* pix, float* df1, int N, int C, int HW, float gscale,
+                                   void* stream) {
+    DCVIC_CHECK_ARG(f0 && f1 && w && pix && N > 0 && N <= 65535, "lpips_tap: bad argument");
+    dim3 grid(dcvic_cdiv(HW, 256), N);
+    lpips_tap_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(f0, f1, w, pix, df1, C, HW, gscale);
+    DCVIC_CHECK_LAUNCH("lpips_tap");
+    return DCVIC_OK;
+}

@@ -7,8 +7,10 @@ Loss definitions: config/exp1_stage1_3.yaml:61-79 (MSELoss x50 on [0,1] images, 
 the predicted code embedding, CrossEntropyLoss x0.5 on the code logits).
 
 Differences, stated:
-  * LPIPS (perceptual_loss, AlexNet weights from the `lpips` wheel) cannot be fetched offline and is NOT part of the loss
-    here (`perceptual` is logged as 0); everything else of calc_g_loss is.
+  * LPIPS (perceptual_loss): the `lpips` wheel and its AlexNet / head weights cannot be fetched offline.  The term is computed
+    by dc_vic_amd/train/lpips.py (architecture restated, state-dict key names of the package) with deterministic synthetic
+    weights unless an `lpips` state dict is loaded into `trainer.lpips` -- parity unpinned.  Pass `loss_weights={'perceptual': 0}`
+    to drop the term.
   * the reference is single-process (README.md:64-65, base_trainer.py:158 TODO); here gradients are averaged across ranks
     with bucketed RCCL all-reduces of the flat gradient buffers -- with world size 1 nothing is sent.
 Training mode changes nothing numerically on the frozen encoder / entropy side for this trainer: with
@@ -99,6 +101,10 @@ class DualBetaCondGanDistortionVqCodeTrainer:
         self.dist = dist
         self.rng = np.random.RandomState(seed)
         self.last_fake: Optional[Tensor] = None
+        self.lpips = None
+        if self.w["perceptual"] > 0:
+            from .lpips import LPIPSAlex
+            self.lpips = LPIPSAlex(seed=0).to(dev)
 
     # hyperprior_dc_vic_model.py:99-110
     def sample_selected_beta_pair(self, n: int) -> Tuple[Tensor, Tensor]:
@@ -130,7 +136,11 @@ class DualBetaCondGanDistortionVqCodeTrainer:
         w = self.w
         log = {}
         log["distortion"] = A.mse_loss(ctx, o["fake"], o["real"], w["distortion"] * 0.25)        # MSELoss on [0,1]: ((a+1)/2-(b+1)/2)^2
-        log["perceptual"] = torch.zeros(1, device=self.device)                                    # LPIPS weights unavailable offline
+        if self.lpips is not None:
+            from .lpips import lpips_loss
+            log["perceptual"] = lpips_loss(ctx, self.lpips, o["real"], o["fake"], w["perceptual"])
+        else:
+            log["perceptual"] = torch.zeros(1, device=self.device)
         g_fake = nets.discriminator_forward(ctx, self.D, o["fake"], beta_rate, beta_vq)
         log["adv"] = A.bce_logits_loss(ctx, g_fake, True, w["gan"])
         log["code_distortion"] = A.mse_loss(ctx, o["pred_embed"], o["gt_vq_latent"], w["code_distortion"])

@@ -313,6 +313,13 @@ int dcvic_clip_scale_f32(const float* sumsq, float max_norm, float* gscale, void
 /* Nearest x2 upsample (down = 0) and its adjoint, the 2x2 block sum (down = 1), on `planes` planes of Hlow x Wlow. */
 int dcvic_resample2_f32(int down, const float* in, float* out, long long planes, int Hlow, int Wlow, void* stream);
 
+/* LPIPS(alex) pieces (src/losses/perceptual_loss.py:10-30; parity unpinned -- the lpips package is not in the reference tree):
+ * zero-padded space-to-depth and its adjoint (the 11x11/s4/p2 stem as a 3x3 conv over 48 channels), MaxPool2d(3, 2) forward
+ * (dx == NULL) / backward, and one tap: per-pixel sum_c w[c] (f0/|f0| - f1/|f1|)^2 plus the gradient w.r.t. f1. */
+int dcvic_s2d_f32(const float* in, float* out, long long planes, int H, int W, int r, int pad, int inverse, void* stream);
+int dcvic_maxpool3s2_f32(const float* x, float* y, unsigned char* argmax, const float* dy, float* dx, long long planes, int H, int W, void* stream);
+int dcvic_lpips_tap_f32(const float* f0, const float* f1, const float* w, float* pix, float* df1, int N, int C, int HW, float gscale, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -19,7 +19,7 @@ import torch.nn.functional as F
 from . import dcvic_oracle as O
 
 TRAINABLE_PREFIXES = ("decoder.", "vq_estimator.", "fusion_module.")
-LOSS_W = dict(distortion=50.0, gan=0.01, code_distortion=1.0, code_ce=0.5)
+LOSS_W = dict(distortion=50.0, perceptual=1.0, gan=0.01, code_distortion=1.0, code_ce=0.5)
 
 
 def discriminator(dsd: Dict[str, torch.Tensor], x: torch.Tensor, b1, b2) -> torch.Tensor:
@@ -34,6 +34,27 @@ def discriminator(dsd: Dict[str, torch.Tensor], x: torch.Tensor, b1, b2) -> torc
     return F.conv2d(h, dsd["main.11.weight"], dsd["main.11.bias"], stride=1, padding=1)
 
 
+def lpips_alex(lsd: Dict[str, torch.Tensor], in0: torch.Tensor, in1: torch.Tensor) -> torch.Tensor:
+    """lpips.LPIPS(net='alex', lpips=True, spatial=False).forward(in0, in1) -> [N, 1, 1, 1], restated from the published model
+    (PARITY UNPINNED: package and weights absent).  `lsd`: state dict with the package's key names."""
+    def feats(x):
+        x = (x - lsd["scaling_layer.shift"]) / lsd["scaling_layer.scale"]
+        f1 = F.relu(F.conv2d(x, lsd["net.slice1.0.weight"], lsd["net.slice1.0.bias"], stride=4, padding=2))
+        f2 = F.relu(F.conv2d(F.max_pool2d(f1, 3, 2), lsd["net.slice2.3.weight"], lsd["net.slice2.3.bias"], padding=2))
+        f3 = F.relu(F.conv2d(F.max_pool2d(f2, 3, 2), lsd["net.slice3.6.weight"], lsd["net.slice3.6.bias"], padding=1))
+        f4 = F.relu(F.conv2d(f3, lsd["net.slice4.8.weight"], lsd["net.slice4.8.bias"], padding=1))
+        f5 = F.relu(F.conv2d(f4, lsd["net.slice5.10.weight"], lsd["net.slice5.10.bias"], padding=1))
+        return [f1, f2, f3, f4, f5]
+
+    def unit(f):
+        return f / (torch.sqrt(torch.sum(f ** 2, dim=1, keepdim=True)) + 1e-10)
+    val = 0
+    for k, (a, b) in enumerate(zip(feats(in0), feats(in1))):
+        d = (unit(a) - unit(b)) ** 2
+        val = val + F.conv2d(d, lsd[f"lin{k}.model.1.weight"]).mean([2, 3], keepdim=True)
+    return val
+
+
 def encode_side(sd, x: torch.Tensor, b1, b2, eb):
     """Frozen part under no_grad: VQGAN encode + VQ, ELIC encoder, hyperprior, CHARM -> y_hat (values of ste_round = round)."""
     with torch.no_grad():
@@ -45,7 +66,7 @@ def encode_side(sd, x: torch.Tensor, b1, b2, eb):
     return z_q, idx, ch["y_hat"], ch["y_likelihood"], z_lik
 
 
-def generator_losses(sd, dsd, x: torch.Tensor, b1, b2, eb, w=LOSS_W):
+def generator_losses(sd, dsd, x: torch.Tensor, b1, b2, eb, w=LOSS_W, lsd=None):
     """calc_g_loss on run_comp_model's output.  `sd` entries under TRAINABLE_PREFIXES should require grad."""
     z_q, idx, y_hat, _, _ = encode_side(sd, x, b1, b2, eb)
     feat_1, feats = O.elic_decoder_feats(sd, y_hat, b1, b2)
@@ -55,6 +76,8 @@ def generator_losses(sd, dsd, x: torch.Tensor, b1, b2, eb, w=LOSS_W):
     fake = O.fusion_decode(sd, lat, feats, 1.0)
     L = {}
     L["distortion"] = w["distortion"] * F.mse_loss((x + 1.0) / 2.0, (fake + 1.0) / 2.0)
+    if lsd is not None:
+        L["perceptual"] = w["perceptual"] * torch.mean(lpips_alex(lsd, x, fake))
     g_fake = discriminator(dsd, fake, b1, b2)
     L["adv"] = w["gan"] * F.binary_cross_entropy_with_logits(g_fake, torch.ones_like(g_fake))
     L["code_distortion"] = w["code_distortion"] * F.mse_loss(z_q, pred_embed)

@@ -240,6 +240,26 @@ def test_losses_and_adam():
         relclose(pd, pt.detach(), 2e-6, f"adam step {step}")
 
 
+def test_lpips_alex_value_and_gradient():
+    """LPIPS(alex) term (architecture restated, synthetic weights -- parity unpinned against the package) vs torch autograd of
+    the same restatement: value and d/d(fake), incl. the 11x11/s4 stem as a space-to-depth 3x3 convolution and MaxPool2d(3, 2)."""
+    from dc_vic_amd.train import autograd as A
+    from dc_vic_amd.train.lpips import LPIPSAlex, lpips_loss
+    from oracle import train_oracle as T
+    L = LPIPSAlex(seed=0).to(DEV)
+    lsd = {k: v.detach().cpu().clone() for k, v in L.state_dict().items()}
+    assert set(lsd) >= {"net.slice1.0.weight", "net.slice2.3.bias", "net.slice5.10.weight", "lin3.model.1.weight", "scaling_layer.shift"}
+    real = torch.rand((2, 3, 64, 96), generator=torch.Generator().manual_seed(95)) * 2 - 1
+    fake = (real + 0.3 * rnd(2, 3, 64, 96, seed=96)).clamp(-1, 1)
+    fr = fake.clone().requires_grad_(True)
+    ref = 0.7 * torch.mean(T.lpips_alex(lsd, real, fr)); ref.backward()
+    ctx = A.Ctx([]); fv = A.Var(fake.to(DEV))
+    val = lpips_loss(ctx, L, real.to(DEV), fv, 0.7)
+    ctx.backward()
+    relclose(val, ref.detach().reshape(1), 2e-5, "lpips value")
+    relclose(fv.grad, fr.grad, 2e-4, "lpips d/dfake")
+
+
 # ------------------------------------------------------------------------------------------------ networks vs the oracle
 @pytest.fixture(scope="module")
 def model():
@@ -282,7 +302,8 @@ def test_generator_and_discriminator_step_vs_oracle(model, synth_sd):
         sd[k].requires_grad_(True)
     dsd = {k: v.clone().requires_grad_(True) for k, v in dsd0.items()}
     eb = EntropyBottleneckOracle(synth_sd, "entropy_model_z")
-    L, oo = T.generator_losses(sd, dsd, x, b1, b2, eb)
+    lsd = {k: v.detach().cpu().clone() for k, v in tr.lpips.state_dict().items()}
+    L, oo = T.generator_losses(sd, dsd, x, b1, b2, eb, lsd=lsd)
     total = sum(L.values())
     total.backward()
     # ---- product: forward + losses + backward (no optimizer yet) for the gradient comparison
@@ -292,7 +313,7 @@ def test_generator_and_discriminator_step_vs_oracle(model, synth_sd):
     assert torch.equal(o["gt_vq_indices"].cpu(), oo["gt_idx"]) and torch.equal(o["out_vq_indices"].cpu(), oo["out_idx"]), "integer decisions differ"
     relclose(o["fake"].data, oo["fake"], 2e-4, "fake images")
     glog = tr.calc_g_loss(ctx, o, b1, b2)
-    for k in ("distortion", "adv", "code_distortion", "code_ce"):
+    for k in ("distortion", "perceptual", "adv", "code_distortion", "code_ce"):
         relclose(glog[k], L[k].detach().reshape(1), 2e-4, f"loss {k}")
     ctx.backward()
     own = dict(model.named_parameters())
