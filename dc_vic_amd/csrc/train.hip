@@ -66,8 +66,10 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_kernel(const WgradArgs a) {
     const int n = slab / a.slabs_per_img, srow0 = (slab % a.slabs_per_img) * a.rows_per_slab;
     const int xw = (PX - 1) * a.stride + a.KW;             // input pixels per chunk row
     const int XS = xw | 1;                                  // odd
-    float* As = sm;                                        // [128][AS]
-    float* Xs = sm + 128 * AS;                             // [32][XS]
+    // double-buffered LDS images; the next chunk's global loads are in flight (registers) while this chunk's MFMAs run
+    const int XSZ = 32 * XS;
+    float* As0 = sm;                                       // 2 x [128][AS]
+    float* Xs0 = sm + 2 * 128 * AS;                        // 2 x [32][XS]
     f32x16 acc[KWT];
 #pragma unroll
     for (int t = 0; t < KWT; ++t)
@@ -77,38 +79,62 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_kernel(const WgradArgs a) {
     const float* Xn = a.X + (long long)n * a.x_bs;
     const int m0 = mb * 128, c0 = cb * 32;
     const int rend = min(srow0 + a.rows_per_slab, a.Hg);
-    for (int oy = srow0; oy < rend; ++oy) {
+    const int cpr = (a.Wg + PX - 1) / PX;                  // chunks per row
+    const int nchunks = max(rend - srow0, 0) * cpr;
+    constexpr int NA = 128 * PX / 256;                     // 16 A elements per thread
+    constexpr int NXMAX = (32 * (31 * 4 + 5) + 255) / 256; // covers stride <= 4, KW <= 5
+    const int nx = (32 * xw + 255) / 256;
+    float ra[NA], rx[NXMAX];
+    auto fetch = [&](int ch) {
+        const int oy = srow0 + ch / cpr, ox0 = (ch % cpr) * PX;
         const int iy = oy * a.stride + ky - a.pt;
         const bool rowok = iy >= 0 && iy < a.Hx;
-        for (int ox0 = 0; ox0 < a.Wg; ox0 += PX) {
-            __syncthreads();
-            for (int e = tid; e < 128 * PX; e += 256) {            // A: G[m0 + r][oy][ox0 + p]
-                const int r = e >> 5, p = e & 31;
-                float v = 0.f;
-                if (m0 + r < a.M && ox0 + p < a.Wg) v = Gn[((long long)(m0 + r) * a.Hg + oy) * a.Wg + ox0 + p];
-                As[r * AS + p] = v;
-            }
-            const int ix0 = ox0 * a.stride - a.pl;
-            for (int e = tid; e < 32 * xw; e += 256) {             // B: X[c0 + c][iy][ix0 + q]
-                const int c = e / xw, q = e - c * xw;
-                const int ix = ix0 + q;
-                float v = 0.f;
-                if (rowok && c0 + c < a.Cx && ix >= 0 && ix < a.Wx) v = Xn[((long long)(c0 + c) * a.Hx + iy) * a.Wx + ix];
-                Xs[c * XS + q] = v;
-            }
-            __syncthreads();
-            const float* ap = As + (wave * 32 + lr) * AS + lh;
-            const float* xp = Xs + lr * XS + lh * a.stride;
-#pragma unroll 4
-            for (int s = 0; s < PX / 2; ++s) {
-                const float av = ap[2 * s];
 #pragma unroll
-                for (int t = 0; t < KWT; ++t) {
-                    const float bv = xp[2 * s * a.stride + t];
-                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[t], 0, 0, 0);
-                }
+        for (int u = 0; u < NA; ++u) {
+            const int e = tid + u * 256, r = e >> 5, p = e & 31;
+            ra[u] = (m0 + r < a.M && ox0 + p < a.Wg) ? Gn[((long long)(m0 + r) * a.Hg + oy) * a.Wg + ox0 + p] : 0.f;
+        }
+        const int ix0 = ox0 * a.stride - a.pl;
+#pragma unroll
+        for (int u = 0; u < NXMAX; ++u) {
+            const int e = tid + u * 256;
+            float v = 0.f;
+            if (u < nx && e < 32 * xw) {
+                const int c = e / xw, q = e - c * xw, ix = ix0 + q;
+                if (rowok && c0 + c < a.Cx && ix >= 0 && ix < a.Wx) v = Xn[((long long)(c0 + c) * a.Hx + iy) * a.Wx + ix];
+            }
+            rx[u] = v;
+        }
+    };
+    auto stage = [&](int buf) {
+        float* As = As0 + buf * 128 * AS;
+        float* Xs = Xs0 + buf * XSZ;
+#pragma unroll
+        for (int u = 0; u < NA; ++u) { const int e = tid + u * 256; As[(e >> 5) * AS + (e & 31)] = ra[u]; }
+#pragma unroll
+        for (int u = 0; u < NXMAX; ++u) {
+            const int e = tid + u * 256;
+            if (u < nx && e < 32 * xw) { const int c = e / xw; Xs[c * XS + (e - c * xw)] = rx[u]; }
+        }
+    };
+    if (nchunks > 0) { fetch(0); stage(0); }
+    __syncthreads();
+    for (int ch = 0; ch < nchunks; ++ch) {
+        const int buf = ch & 1;
+        if (ch + 1 < nchunks) fetch(ch + 1);
+        const float* ap = As0 + buf * 128 * AS + (wave * 32 + lr) * AS + lh;
+        const float* xp = Xs0 + buf * XSZ + lr * XS + lh * a.stride;
+#pragma unroll 4
+        for (int s = 0; s < PX / 2; ++s) {
+            const float av = ap[2 * s];
+#pragma unroll
+            for (int t = 0; t < KWT; ++t) {
+                const float bv = xp[2 * s * a.stride + t];
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[t], 0, 0, 0);
             }
         }
+        if (ch + 1 < nchunks) stage(buf ^ 1);              // everyone finished reading buf ^ 1 before the previous barrier
+        __syncthreads();
     }
     // partial[slab][m][c][ky][kx]; accumulator: col = lane%32 -> c, row = (r&3) + 8 (r>>2) + 4 (lane>>5) -> m
     float* P = a.part + (long long)slab * a.M * a.Cx * a.KH * a.KW;
@@ -162,7 +188,7 @@ extern "C" int dcvic_conv_wgrad_f32(const float* G, long long g_bs, int M, int H
     const long long blocks = (long long)a.mblocks * a.cblocks * KH * slabs;
     DCVIC_CHECK_ARG(blocks < (1ll << 31), "conv_wgrad: grid too large");
     const int xw = 31 * stride + KW;
-    const size_t lds = (size_t)(128 * 33 + 32 * (xw | 1)) * sizeof(float);
+    const size_t lds = (size_t)2 * (128 * 33 + 32 * (xw | 1)) * sizeof(float);
     hipStream_t st = (hipStream_t)stream;
     switch (KW) {
         case 1: conv_wgrad_kernel<1><<<(unsigned)blocks, 256, lds, st>>>(a); break;
@@ -488,22 +514,23 @@ __global__ __launch_bounds__(64) void swin_attn_bwd_kernel(const float* __restri
         dbase[(long long)(2 * C + head * hd + d) * HWl + pix] = dv[d];
     }
 }
-// dtable[rel][head] (+)= sum over (n, window) ascending, then over the (i, j) pairs of that relative offset ascending
-__global__ void swin_bias_grad_kernel(const float* __restrict__ dSp, float* __restrict__ dtable, int nwin_total, int heads, int ws, int accumulate) {
-    const int T = ws * ws, R = (2 * ws - 1) * (2 * ws - 1);
-    const int id = blockIdx.x * blockDim.x + threadIdx.x;
-    if (id >= R * heads) return;
+// dtable[rel][head] (+)= sum over all (n, window) and over the (i, j) pairs of that relative offset.  One wave per table entry:
+// lane l sums windows l, l + 64, ... (pairs ascending inside a window), then a fixed xor-shuffle tree -> deterministic.
+__global__ __launch_bounds__(64) void swin_bias_grad_kernel(const float* __restrict__ dSp, float* __restrict__ dtable, int nwin_total, int heads, int ws, int accumulate) {
+    const int T = ws * ws;
+    const int id = blockIdx.x;
     const int rel = id / heads, head = id % heads;
     const int dy = rel / (2 * ws - 1) - (ws - 1), dx = rel % (2 * ws - 1) - (ws - 1);
-    float s = accumulate ? dtable[id] : 0.f;
-    for (int w = 0; w < nwin_total; ++w) {
+    float s = 0.f;
+    for (int w = threadIdx.x; w < nwin_total; w += 64) {
         const float* D = dSp + ((long long)w * heads + head) * T * T;
         for (int i = 0; i < T; ++i) {
             const int jy = i / ws - dy, jx = i % ws - dx;
             if (jy >= 0 && jy < ws && jx >= 0 && jx < ws) s += D[i * T + jy * ws + jx];
         }
     }
-    dtable[id] = s;
+    s = wsum_f(s);
+    if (threadIdx.x == 0) dtable[id] = (accumulate ? dtable[id] : 0.f) + s;
 }
 extern "C" int dcvic_swin_attn_bwd_f32(const float* qkv, const float* dout, float* dqkv, const float* table, float* dtable, float* dS_workspace,
                                        int N, int C, int H, int W, int heads, int ws, int shift, int accumulate, void* stream) {
@@ -513,7 +540,7 @@ extern "C" int dcvic_swin_attn_bwd_f32(const float* qkv, const float* dout, floa
     swin_attn_bwd_kernel<<<nwin * heads, 64, 0, (hipStream_t)stream>>>(qkv, dout, dqkv, table, dS_workspace, C, H, W, heads, ws, shift);
     DCVIC_CHECK_LAUNCH("swin_attn_bwd");
     const int R = (2 * ws - 1) * (2 * ws - 1);
-    swin_bias_grad_kernel<<<dcvic_cdiv(R * heads, 64), 64, 0, (hipStream_t)stream>>>(dS_workspace, dtable, nwin, heads, ws, accumulate);
+    swin_bias_grad_kernel<<<R * heads, 64, 0, (hipStream_t)stream>>>(dS_workspace, dtable, nwin, heads, ws, accumulate);
     DCVIC_CHECK_LAUNCH("swin_bias_grad");
     return DCVIC_OK;
 }
