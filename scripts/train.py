@@ -12,7 +12,8 @@ all-reduces of the flat gradient buffers (the reference is single-GPU, README.md
 or seeded synthetic tensors.  Checkpoints use the reference's file format: `comp_model_iterXXXXXXX.pth.tar` =
 {'iter', 'comp_model': state_dict}, `discriminator_iter...` = {'iter', 'discriminator': state_dict} (model_saver.py:39-46).
 The optimizer / loss settings are the YAML's `optim` / `loss` sections when present (config/exp1_stage1_3.yaml:43-79), else
-their stage-3 values.  LPIPS is not part of the loss (its AlexNet weights cannot be fetched offline; see trainer.py).
+their stage-3 values.  LPIPS runs on synthetic AlexNet weights unless a state dict of the `lpips` package is loaded into
+`trainer.lpips` (its weights cannot be fetched offline; see trainer.py).
 """
 from __future__ import annotations
 

@@ -54,7 +54,7 @@ def main():
     if rank == 0:
         print(json.dumps({"metric": "training samples/sec, stage-3 G+D step @256x256", "value": world * a.batch * a.steps / dt, "unit": "samples/s",
                           "n_gpus": world, "steps": a.steps, "ms_per_step": 1e3 * dt / a.steps, "batch_per_gpu": a.batch, "dtype": "f32",
-                          "data": "synthetic", "lpips": "excluded (weights unavailable offline)", "last_log": log}), flush=True)
+                          "data": "synthetic", "lpips": "included, synthetic weights (parity unpinned)", "last_log": log}), flush=True)
     if dist is not None:
         dist.destroy_process_group()
 
