@@ -200,3 +200,28 @@ def test_binary_rate_search_script(tmp_path):
     top = pd.read_csv(sel / "beta_selection_results.csv")
     assert list(top.columns) == ["target_rate", "selected_beta_vq", "selected_beta_rate"] and len(top) == 1
     assert top.iloc[0]["selected_beta_vq"] == res.iloc[0]["beta_vq"]
+
+
+def test_train_cli_synthetic(tmp_path):
+    """scripts/train.py (reference scripts/train.py:16-27 + train_loop): three stage-3 G + D iterations on synthetic crops, the
+    log line per iteration, and checkpoints in the reference's file format ({'iter', 'comp_model'} / {'iter', 'discriminator'})
+    that load back through load_learned_weight."""
+    import torch
+    out = tmp_path / "ckpt"
+    cmd = [sys.executable, os.path.join(ROOT, "scripts", "train.py"), os.path.join(ROOT, "config", "dc_vic_synthetic.yaml"), "--synthetic_weights",
+           "--synthetic_data", "--batch_size", "2", "--total_iter", "3", "--save_dir", str(out), "--save_step", "3", "--log_step", "1"]
+    res = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True)
+    assert res.returncode == 0, res.stderr[-2000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.startswith("iter")]
+    assert len(lines) == 3 and all("samples/s" in ln and "distortion" in ln and "perceptual" in ln and "d_total" in ln for ln in lines), res.stdout
+    ck = torch.load(out / "comp_model_iter0000003.pth.tar", map_location="cpu", weights_only=True)
+    assert ck["iter"] == 3 and "decoder.conv1.weight" in ck["comp_model"] and "vq_model.decoder.conv_in.weight" in ck["comp_model"]
+    dk = torch.load(out / "discriminator_iter0000003.pth.tar", map_location="cpu", weights_only=True)
+    assert sorted(k for k in dk["discriminator"] if k.startswith("main.")) == [f"main.{i}.{p}" for i in (0, 11, 2, 5, 8) for p in ("bias", "weight")]
+    from dc_vic_amd import BaseConfig, build_comp_model
+    m = build_comp_model(BaseConfig.fromfile(os.path.join(ROOT, "config", "dc_vic_synthetic.yaml"), {"device": "cuda:0"}))
+    m.load_learned_weight(str(out / "comp_model_iter0000003.pth.tar"))
+    from dc_vic_amd.synth import full_synth_state_dict
+    sd = full_synth_state_dict(1234)
+    assert torch.equal(m.state_dict()["encoder.conv1.weight"].cpu(), sd["encoder.conv1.weight"])            # frozen: untouched
+    assert not torch.equal(m.state_dict()["decoder.conv1.weight"].cpu(), sd["decoder.conv1.weight"])       # trained
