@@ -1,0 +1,355 @@
+// wino.hip -- 3x3 / stride-1 / pad-1 convolution as Winograd F(2x2, 3x3) on fp32 MFMA, gfx950.
+//
+// Replaces the same torch.nn.Conv2d(k3, s1, p1) layers as conv3x3.hip, but ONLY where no integer decision depends on the
+// result bit for bit: the frozen VQGAN decoder + SFT fusion after the estimator's argmax (ldm/modules/diffusionmodules/
+// model.py:82-141, 462-568; src/models/layer/codeformer_layers.py:20-67; src/models/subnet/vq_fusion_module.py:78-126).
+// Everything that feeds the VQ argmin, the rANS symbols / cdf indexes or the estimator argmax stays on the direct kernels,
+// whose reduction order is the layer-defined fmaf chain.  Winograd re-associates: Y = A^T [ sum_ci (G g G^T) . (B^T d B) ] A
+// executes 16 multiplies per 2x2 outputs and input channel instead of 36 (4/9 of the MFMA work) and differs from the
+// direct sum at the 1e-6 relative level (tolerances in tests/test_gpu_kernels.py::test_wino_*).
+//
+// One workgroup = 512 threads = 8 waves (2 per SIMD) on 64 output channels x (8 rows x 32 columns) = 64 tiles of 2x2.
+//   * a pipeline stage is 8 input channels.  Per stage the raw input patch (8 ch x 10 x 34, zero padded through a zero
+//     word) and the pre-transformed weights U (16 positions x 8 ch x 64 co = 32 KiB, packed by wino_pack_kernel in the
+//     exact LDS image) arrive by LDS-DMA (`global_load_lds_dword / _dwordx4`), two stages / one stage ahead;
+//   * every thread transforms ONE (channel, tile) 4x4 patch per stage (8 ds_read_b64, 32 adds, 16 ds_write_b32) into the
+//     V image of the NEXT stage while the MFMAs of the current stage run;
+//   * wave w owns Winograd positions 2w and 2w+1: per position a 64 x 64 (co x tile) GEMM block as 2 x 2
+//     `v_mfma_f32_32x32x2_f32` accumulators (128 accumulator registers per lane).  The U and V images are laid out so that
+//     ONE ds_read_b128 per operand feeds two k-steps x two 32-blocks (8 MFMAs): word ((q*2 + kpar)*32 + m)*4 + ksq*2 + blk
+//     of a position's 512-word slab holds channel 4q + 2ksq + kpar, row/column blk*32 + m;
+//   * epilogue: the 16 positions of a (co, tile) pair live in 8 different waves -> exchanged through LDS in two rounds of
+//     32 output channels (128 KiB, the staging buffers are dead by then), A^T M A, bias -> act -> (+res) -> float2 stores.
+// LDS: 2 x 12 KiB raw patch + 2 x 32 KiB U + 2 x 32 KiB V + bias row = 152.25 KiB: one workgroup per CU.
+// Deterministic and batch-invariant: per position the reduction runs over chunks ascending, then k-steps ascending inside
+// the MFMA's ordered fmaf chain; the tiling never depends on N.
+#include "conv_common.h"
+
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+
+__device__ float dcvic_wino_zero[16];   // zero-initialised: source of padded lanes
+
+#define WN_TH 8
+#define WN_TW 32
+#define WN_PW 34
+#define WN_PLANE 340
+#define WN_CO 64
+#define WN_THREADS 512
+#define WN_XSLOTS 6
+#define WN_XS 3072
+#define WN_US 8192
+#define WN_VS 8192
+#define WN_OFF_U (2 * WN_XS)
+#define WN_OFF_V (WN_OFF_U + 2 * WN_US)
+#define WN_OFF_BIAS (WN_OFF_V + 2 * WN_VS)
+#define WN_LDS_FLOATS (WN_OFF_BIAS + WN_CO)
+
+// U = G g G^T of one (co, ci) 3x3 kernel, position p = 4a + b
+__device__ __forceinline__ double wino_u(const float* g, int a, int b) {
+    const double G[4][3] = {{1.0, 0.0, 0.0}, {0.5, 0.5, 0.5}, {0.5, -0.5, 0.5}, {0.0, 0.0, 1.0}};
+    double s = 0.0;
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) s += G[a][r] * (double)g[r * 3 + c] * G[b][c];
+    return s;
+}
+
+// packed[cotile][chunk][p 16][q 2][kpar 2][m 32][ksq 2][mt 2]  <-  w[Cout][Cin][3][3]   (fp64 transform, rounded once)
+__global__ void wino_pack_kernel(const float* __restrict__ w, float* __restrict__ wp, int Cin, int Cout, int n_chunks, long long total) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    long long r = i;
+    const int mt = r & 1; r >>= 1;
+    const int ksq = r & 1; r >>= 1;
+    const int m = r & 31; r >>= 5;
+    const int kpar = r & 1; r >>= 1;
+    const int q = r & 1; r >>= 1;
+    const int p = r & 15; r >>= 4;
+    const int chunk = (int)(r % n_chunks);
+    const int cotile = (int)(r / n_chunks);
+    const int co = cotile * WN_CO + mt * 32 + m, ci = chunk * KC + 4 * q + 2 * ksq + kpar;
+    float v = 0.f;
+    if (co < Cout && ci < Cin) v = (float)wino_u(w + ((long long)co * Cin + ci) * 9, p >> 2, p & 3);
+    wp[i] = v;
+}
+
+__global__ __launch_bounds__(WN_THREADS, 2) void conv3x3_wino_kernel(const ConvKArgs K) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // 0..7
+
+    int b;
+    {
+        const int orig = blockIdx.x, nb = K.nblocks;
+        const int q = nb / NXCD, r = nb % NXCD, x = orig % NXCD;
+        b = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + orig / NXCD;
+    }
+    const int cotile = b % K.n_cotiles; b /= K.n_cotiles;
+    const int tile_x = b % K.tiles_x; b /= K.tiles_x;
+    const int tile_y = b % K.tiles_y; b /= K.tiles_y;
+    const int n = b;
+    const int oy0 = tile_y * WN_TH, ox0 = tile_x * WN_TW;
+    const int iy0 = oy0 - 1, ix0 = ox0 - 1;
+    const long long HW = (long long)K.H * K.W;
+
+    // ---- raw-patch DMA slots: element e = tid + s*512 of [8 ch][10][34]; running pointers advanced per stage
+    const float* xp[WN_XSLOTS];
+    unsigned xst[WN_XSLOTS];
+    int poff[WN_XSLOTS];
+#pragma unroll
+    for (int s = 0; s < WN_XSLOTS; ++s) {
+        const int e = tid + s * WN_THREADS;
+        int o = -1;
+        if (e < KC * WN_PLANE) {
+            const int k = e / WN_PLANE, r = e - k * WN_PLANE;
+            const int py = r / WN_PW, px = r - py * WN_PW;
+            const int iy = iy0 + py, ix = ix0 + px;
+            if (iy >= 0 && iy < K.H && ix >= 0 && ix < K.W) o = (int)(k * HW) + iy * K.W + ix;
+        }
+        poff[s] = o;
+        xst[s] = o >= 0 ? (unsigned)(KC * HW * 4) : 0u;
+    }
+    int x_left = 0;
+    auto x_rebase = [&](int c) {                                  // pointers for absolute input channel c
+        int si = 0;
+        if (c >= K.srcC[0]) { c -= K.srcC[0]; si = 1; if (c >= K.srcC[1]) { c -= K.srcC[1]; si = 2; } }
+        const float* base = K.src[si] + (long long)n * K.src_bs[si] + (long long)c * HW;
+#pragma unroll
+        for (int s = 0; s < WN_XSLOTS; ++s) xp[s] = poff[s] >= 0 ? base + poff[s] : dcvic_wino_zero;
+        x_left = K.srcC[si] - c;
+    };
+    x_rebase(0);
+    const int n_stages = K.n_chunks;
+    int x_next = 0;                                               // chunk the pointers stand at
+    auto issue_x = [&](int buf) {
+        float* xb = smem + buf * WN_XS;
+#pragma unroll
+        for (int s = 0; s < WN_XSLOTS; ++s)
+            __builtin_amdgcn_global_load_lds(xp[s], (lds_ptr_t)(xb + wave * 64 + s * WN_THREADS), 4, 0, 0);
+        ++x_next;
+        x_left -= KC;
+        if (x_left > 0) {
+#pragma unroll
+            for (int s = 0; s < WN_XSLOTS; ++s) xp[s] = reinterpret_cast<const float*>(reinterpret_cast<const char*>(xp[s]) + xst[s]);
+        } else if (x_next < n_stages) {
+            x_rebase(x_next * KC);
+        }
+    };
+
+    // ---- weight DMA: the stage's 32 KiB slab is already the LDS image; thread moves float4 #(tid + j*512)
+    const float* wp4[4];
+    {
+        const float* wbase = K.wp + (long long)cotile * K.n_chunks * (long long)WN_US;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) wp4[j] = wbase + 4 * (tid + j * WN_THREADS);
+    }
+    auto issue_u = [&](int buf) {
+        float* ub = smem + WN_OFF_U + buf * WN_US;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            __builtin_amdgcn_global_load_lds(reinterpret_cast<const float4*>(wp4[j]), (lds_ptr_t)(ub + (wave * 64 + j * WN_THREADS) * 4), 16, 0, 0);
+            wp4[j] += WN_US;
+        }
+    };
+
+    // ---- input transform: this thread's (channel, tile) of a stage
+    //   wave -> (q, kpar, jhalf); lane -> (j16, nt, ksq);  channel 4q + 2ksq + kpar, tile row 2nt + jhalf, tile column j16
+    const int t_q = wave >> 2, t_kpar = (wave >> 1) & 1, t_jhalf = wave & 1;
+    const int t_j16 = lane & 15, t_nt = (lane >> 4) & 1, t_ksq = lane >> 5;
+    const int t_src = (4 * t_q + 2 * t_ksq + t_kpar) * WN_PLANE + (2 * (2 * t_nt + t_jhalf)) * WN_PW + 2 * t_j16;
+    const int t_dst = ((t_q * 2 + t_kpar) * 32 + t_jhalf * 16 + t_j16) * 4 + t_ksq * 2 + t_nt;
+    auto transform = [&](int xbuf, int vbuf) {
+        const float* xr = smem + xbuf * WN_XS + t_src;
+        float d[4][4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float2 lo = *reinterpret_cast<const float2*>(xr + r * WN_PW);
+            const float2 hi = *reinterpret_cast<const float2*>(xr + r * WN_PW + 2);
+            d[r][0] = lo.x; d[r][1] = lo.y; d[r][2] = hi.x; d[r][3] = hi.y;
+        }
+        float t[4][4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            t[0][c] = d[0][c] - d[2][c];
+            t[1][c] = d[1][c] + d[2][c];
+            t[2][c] = d[2][c] - d[1][c];
+            t[3][c] = d[1][c] - d[3][c];
+        }
+        float* vw = smem + WN_OFF_V + vbuf * WN_VS + t_dst;
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            vw[(4 * a + 0) * 512] = t[a][0] - t[a][2];
+            vw[(4 * a + 1) * 512] = t[a][1] + t[a][2];
+            vw[(4 * a + 2) * 512] = t[a][2] - t[a][1];
+            vw[(4 * a + 3) * 512] = t[a][1] - t[a][3];
+        }
+    };
+
+    f32x16 acc[2][2][2];                                          // [position of the wave][mt][nt]
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int k = 0; k < 2; ++k)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][k][r] = 0.f;
+
+    const int op_off = (2 * wave) * 512 + lane * 4;               // this lane's float4 of the wave's first position
+    auto mfma_stage = [&](int ubuf, int vbuf) {
+        const float* ua = smem + WN_OFF_U + ubuf * WN_US + op_off;
+        const float* va = smem + WN_OFF_V + vbuf * WN_VS + op_off;
+        dcvic_static_for<0, 4>([&](auto g_) {
+            constexpr int g = decltype(g_)::value, pi = g >> 1, q = g & 1;
+            const float4 A = *reinterpret_cast<const float4*>(ua + pi * 512 + q * 256);
+            const float4 B = *reinterpret_cast<const float4*>(va + pi * 512 + q * 256);
+            const float a4[4] = {A.x, A.y, A.z, A.w}, b4[4] = {B.x, B.y, B.z, B.w};
+#pragma unroll
+            for (int ksq = 0; ksq < 2; ++ksq)
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < 2; ++nt)
+                        acc[pi][mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[ksq * 2 + mt], b4[ksq * 2 + nt], acc[pi][mt][nt], 0, 0, 0);
+        });
+    };
+
+    // ---- pipeline
+    float* const sbias = smem + WN_OFF_BIAS;
+    if (tid < WN_CO) sbias[tid] = K.bias ? K.bias[min(cotile * WN_CO + tid, K.Cout - 1)] : 0.f;
+    issue_x(0);
+    issue_u(0);
+    if (n_stages > 1) issue_x(1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    transform(0, 0);
+    __syncthreads();
+    for (int s = 0; s < n_stages; ++s) {
+        const int cur = s & 1, nxt = cur ^ 1;
+        if (s + 2 < n_stages) issue_x(cur);                       // X(s+2) over X(s), transformed during stage s-1
+        if (s + 1 < n_stages) {
+            issue_u(nxt);
+            transform(nxt, nxt);                                  // X(s+1) -> V(s+1)
+        }
+        mfma_stage(cur, cur);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+
+    // ---- epilogue: exchange through LDS, A^T M A, bias -> act -> (+res) -> store
+    float* const E = smem;                                        // [16 positions][32 co][64 tiles]
+    const int lane_j = lane & 31, lane_k = lane >> 5;
+    const int ty = lane >> 4, tx = lane & 15;
+    const int oy = oy0 + 2 * ty, ox = ox0 + 2 * tx;
+    const bool in_x = ox < K.W, in_y0 = oy < K.H, in_y1 = oy + 1 < K.H;
+    const long long pix = (long long)oy * K.W + ox;
+    float* const ob = K.out + (long long)n * K.out_bs + pix;
+    const float* const rb = K.res ? K.res + (long long)n * K.res_bs + pix : nullptr;
+    const int act = K.act;
+    const bool has_bias = K.bias != nullptr;
+    dcvic_static_for<0, 2>([&](auto h_) {
+        constexpr int h = decltype(h_)::value;
+        if (h) __syncthreads();
+#pragma unroll
+        for (int pi = 0; pi < 2; ++pi)
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    E[((2 * wave + pi) * 32 + 8 * (r >> 2) + 4 * lane_k + (r & 3)) * 64 + nt * 32 + lane_j] = acc[pi][h][nt][r];
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int col = wave * 4 + i;                          // channel inside this round's 32
+            float m[16];
+#pragma unroll
+            for (int p = 0; p < 16; ++p) m[p] = E[(p * 32 + col) * 64 + lane];
+            float s0[4], s1[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                s0[c] = m[c] + m[4 + c] + m[8 + c];
+                s1[c] = m[4 + c] - m[8 + c] - m[12 + c];
+            }
+            float y00 = s0[0] + s0[1] + s0[2], y01 = s0[1] - s0[2] - s0[3];
+            float y10 = s1[0] + s1[1] + s1[2], y11 = s1[1] - s1[2] - s1[3];
+            const int co = cotile * WN_CO + h * 32 + col;
+            if (co < K.Cout && in_x) {
+                if (has_bias) { const float bv = sbias[h * 32 + col]; y00 += bv; y01 += bv; y10 += bv; y11 += bv; }
+                y00 = dcvic_act(y00, act); y01 = dcvic_act(y01, act); y10 = dcvic_act(y10, act); y11 = dcvic_act(y11, act);
+                const long long co_off = (long long)co * HW;
+                if (in_y0) {
+                    if (rb) { const float2 rv = *reinterpret_cast<const float2*>(rb + co_off); y00 += rv.x; y01 += rv.y; }
+                    *reinterpret_cast<float2*>(ob + co_off) = make_float2(y00, y01);
+                }
+                if (in_y1) {
+                    if (rb) { const float2 rv = *reinterpret_cast<const float2*>(rb + co_off + K.W); y10 += rv.x; y11 += rv.y; }
+                    *reinterpret_cast<float2*>(ob + co_off + K.W) = make_float2(y10, y11);
+                }
+            }
+        }
+    });
+}
+
+extern "C" size_t dcvic_wino_packed_bytes(int Cin, int Cout) {
+    if (Cin <= 0 || Cout <= 0) return 0;
+    return (size_t)((Cout + WN_CO - 1) / WN_CO) * ((Cin + KC - 1) / KC) * WN_US * sizeof(float);
+}
+
+extern "C" int dcvic_wino_pack_f32(const float* w, float* packed, int Cin, int Cout, void* stream) {
+    DCVIC_CHECK_ARG(w && packed && Cin > 0 && Cout > 0, "wino_pack: bad argument");
+    const int n_chunks = (Cin + KC - 1) / KC;
+    const long long total = (long long)((Cout + WN_CO - 1) / WN_CO) * n_chunks * WN_US;
+    wino_pack_kernel<<<dcvic_cdiv(total, 256), 256, 0, (hipStream_t)stream>>>(w, packed, Cin, Cout, n_chunks, total);
+    DCVIC_CHECK_LAUNCH("wino_pack");
+    return DCVIC_OK;
+}
+
+extern "C" int dcvic_conv3x3_wino_f32(int Cin, int Cout, const float* packed, const dcvic_conv_io* io, void* stream) {
+    DCVIC_CHECK_ARG(packed && io && io->out && Cin > 0 && Cout > 0, "conv3x3_wino: null pointer");
+    DCVIC_CHECK_ARG(io->n_src >= 1 && io->n_src <= DCVIC_MAX_SRC, "conv3x3_wino: n_src %d", io->n_src);
+    int csum = 0;
+    for (int i = 0; i < io->n_src; ++i) {
+        DCVIC_CHECK_ARG(io->src[i].ptr && io->src[i].C > 0 && io->src[i].C % KC == 0, "conv3x3_wino: source %d needs a multiple of 8 channels", i);
+        DCVIC_CHECK_ARG(io->src[i].batch_stride >= (long long)io->src[i].C * io->H * io->W, "conv3x3_wino: source %d batch stride too small", i);
+        DCVIC_CHECK_ARG((reinterpret_cast<uintptr_t>(io->src[i].ptr) & 3) == 0, "conv3x3_wino: source %d misaligned", i);
+        csum += io->src[i].C;
+    }
+    DCVIC_CHECK_ARG(csum == Cin, "conv3x3_wino: sources carry %d channels, layer expects %d", csum, Cin);
+    DCVIC_CHECK_ARG(io->N > 0 && io->H > 0 && io->W > 0, "conv3x3_wino: bad sizes");
+    DCVIC_CHECK_ARG(io->Hout == io->H && io->Wout == io->W && io->Hfull == io->H && io->Wfull == io->W && io->osy == 1 && io->osx == 1 &&
+                    io->ooy == 0 && io->oox == 0, "conv3x3_wino: stride-1 pad-1 geometry only");
+    DCVIC_CHECK_ARG((io->W & 1) == 0, "conv3x3_wino: width must be even");
+    DCVIC_CHECK_ARG(!io->aff_scale && !io->aff_shift && !io->init, "conv3x3_wino: affine / init epilogues are not supported");
+    DCVIC_CHECK_ARG((long long)io->H * io->W * KC < (1ll << 31), "conv3x3_wino: plane too large");
+    DCVIC_CHECK_ARG(io->out_batch_stride >= (long long)Cout * io->H * io->W && (io->out_batch_stride & 1) == 0 &&
+                    (reinterpret_cast<uintptr_t>(io->out) & 7) == 0, "conv3x3_wino: output view must be 8-byte aligned");
+    DCVIC_CHECK_ARG(!io->res || (io->res_batch_stride >= (long long)Cout * io->H * io->W && (io->res_batch_stride & 1) == 0 &&
+                                 (reinterpret_cast<uintptr_t>(io->res) & 7) == 0), "conv3x3_wino: residual view must be 8-byte aligned");
+    ConvKArgs K;
+    memset(&K, 0, sizeof(K));
+    K.Cin = Cin; K.Cout = Cout; K.T = 9; K.stride = 1;
+    K.N = io->N; K.H = io->H; K.W = io->W; K.Hout = io->H; K.Wout = io->W; K.Hfull = io->H; K.Wfull = io->W;
+    K.osy = K.osx = 1;
+    for (int i = 0; i < DCVIC_MAX_SRC; ++i) {
+        if (i < io->n_src) { K.src[i] = io->src[i].ptr; K.srcC[i] = io->src[i].C; K.src_bs[i] = io->src[i].batch_stride; }
+        else { K.src[i] = io->src[0].ptr; K.srcC[i] = 1 << 30; K.src_bs[i] = 0; }
+    }
+    K.out = io->out; K.out_bs = io->out_batch_stride; K.bias = io->bias; K.act = io->act;
+    K.res = io->res; K.res_bs = io->res_batch_stride;
+    K.wp = packed;
+    K.n_chunks = (Cin + KC - 1) / KC;
+    K.n_cotiles = (Cout + WN_CO - 1) / WN_CO;
+    K.tiles_y = (io->H + WN_TH - 1) / WN_TH;
+    K.tiles_x = (io->W + WN_TW - 1) / WN_TW;
+    const long long blocks = (long long)io->N * K.tiles_y * K.tiles_x * K.n_cotiles;
+    DCVIC_CHECK_ARG(blocks < (1ll << 31), "conv3x3_wino: grid too large");
+    K.nblocks = (int)blocks;
+    static std::atomic<unsigned> attr_mask{0};
+    if (dcvic_first_use_on_device(attr_mask))
+        hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_wino_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    conv3x3_wino_kernel<<<K.nblocks, WN_THREADS, WN_LDS_FLOATS * sizeof(float), (hipStream_t)stream>>>(K);
+    DCVIC_CHECK_LAUNCH("conv3x3_wino");
+    return DCVIC_OK;
+}

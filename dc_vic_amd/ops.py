@@ -64,6 +64,8 @@ def conv_kernel_name(variant: int) -> str:
         return "void conv3x3_dma_kernel<2, 2, 8, 128>(ConvKArgs)"
     if variant == 9003:
         return "void conv3x3_dma_kernel<3, 3, 4, 96>(ConvKArgs)"
+    if variant == 9100:
+        return "conv3x3_wino_kernel(ConvKArgs)"
     if 7000 <= variant < 8000:                       # conv1x1.hip: 7000 + cls
         return f"void conv1x1_dma_kernel<{(128, 64, 32, 96)[variant - 7000]}>(ConvKArgs)"
     if 8500 <= variant < 9000:                       # conv_async16.hip: 8500 + cls*100 + P/32 (tiles in units of 16)
@@ -117,6 +119,11 @@ def shape_stats_report() -> str:
 
 
 # ------------------------------------------------------------------------------------------- conv
+# Winograd F(2x2,3x3) for the layers that opted in (ConvPlan.wino): DCVIC_WINO=0 keeps every layer on the direct kernels
+WINO_ENABLED = os.environ.get("DCVIC_WINO", "1") != "0"
+WINO_MIN_BLOCKS = int(os.environ.get("DCVIC_WINO_MIN_BLOCKS", "192"))
+
+
 class ConvPlan:
     """A convolution layer bound to the C ABI: descriptor(s) + packed weights.
 
@@ -136,6 +143,8 @@ class ConvPlan:
             w = w.view(w.shape[0], w.shape[1], 1, 1)
         self._w = w
         self.phases: List[list] = []      # [desc, {tile class: packed weights}, py, px]
+        self.wino = False                 # set by the owner: Winograd F(2x2,3x3) allowed (no integer decision downstream)
+        self._wino_pack = None
         self.ups_phases = False
         if kind == "conv" and upsample and tuple(w.shape[2:]) == (3, 3) and pad == (1, 1) and stride == 1 \
                 and os.environ.get("DCVIC_UPS_PHASES", "1") != "0":
@@ -197,6 +206,17 @@ class ConvPlan:
             self.phases.append([d, {}, py, px])
             self._wphase.append(wp.detach().contiguous())
         return self
+
+    def _wino_ok(self, srcs, N: int, H: int, W: int) -> bool:
+        """Winograd eligibility: Conv2d(k3, s1, p1), 8-channel-aligned sources, even width, and a grid that fills the chip
+        (64 channels x 8 x 32 pixels per workgroup, one workgroup per CU)."""
+        if self.kind != "conv" or self.upsample or self.ups_phases or self.stride != 1 or self.pad != (1, 1) \
+                or (self.KH, self.KW) != (3, 3) or self._w is None:
+            return False
+        if (W & 1) or self.Cout < 48 or any(s.shape[1] % 8 for s in srcs):
+            return False
+        blocks = N * ((H + 7) // 8) * ((W + 31) // 32) * ((self.Cout + 63) // 64)
+        return blocks >= WINO_MIN_BLOCKS
 
     @staticmethod
     def _pack(d: ConvDesc, w: Tensor) -> Tensor:
@@ -265,6 +285,23 @@ class ConvPlan:
             if sc.shape[0] not in (1, N):
                 raise ValueError("conv affine batch must be 1 or N")
         st = _stream()
+        if self.wino and WINO_ENABLED and init is None and affine is None and self._wino_ok(srcs, N, H, W):
+            if self._wino_pack is None:
+                nbytes = lib().dcvic_wino_packed_bytes(self.Cin, self.Cout)
+                self._wino_pack = torch.empty(nbytes // 4, dtype=torch.float32, device=self._w.device)
+                check(lib().dcvic_wino_pack_f32(_p(self._w), _p(self._wino_pack), self.Cin, self.Cout, st), "wino_pack")
+            io.Hout, io.Wout = Hf, Wf
+            io.osy = io.osx = 1
+            io.ooy = io.oox = 0
+            if _EVENTS is not None:
+                e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+                e0.record()
+                check(lib().dcvic_conv3x3_wino_f32(self.Cin, self.Cout, _p(self._wino_pack), C.byref(io), st), "conv3x3_wino")
+                e1.record()
+                _EVENTS.append((9100, 2.0 * N * H * W * self.Cout * self.Cin * 9, e0, e1, (self.Cin, self.Cout, 9, 1, 0, H, W, N)))
+            else:
+                check(lib().dcvic_conv3x3_wino_f32(self.Cin, self.Cout, _p(self._wino_pack), C.byref(io), st), "conv3x3_wino")
+            return out
         for phi, ph in enumerate(self.phases):
             d, packs, py, px = ph
             if self.ups_phases or (self.kind == "convT" and self.KH == 5):

@@ -137,6 +137,19 @@ size_t dcvic_conv_packed_bytes(const dcvic_conv_desc* d);
 int dcvic_conv_pack_f32(const dcvic_conv_desc* d, const float* w, float* packed, void* stream);
 int dcvic_conv2d_f32(const dcvic_conv_desc* d, const float* packed, const dcvic_conv_io* io, void* stream);
 
+/* Conv2d(k3, s1, p1) as Winograd F(2x2, 3x3) on fp32 MFMA (csrc/wino.hip): 4/9 of the multiplies of the direct sum,
+ * re-associated -- results differ from dcvic_conv2d_f32 at the 1e-6 relative level, so it replaces ONLY the layers
+ * after the last integer decision of the path: the frozen VQGAN decoder and the SFT fusion blocks
+ *   ldm/modules/diffusionmodules/model.py:82-141 (ResnetBlock convs), :462-568 (Decoder);
+ *   src/models/layer/codeformer_layers.py:20-67; src/models/subnet/vq_fusion_module.py:78-126.
+ * Same io contract as dcvic_conv2d_f32 restricted to: Hout = Hfull = H, Wout = Wfull = W (W even), no scatter, every
+ * source a multiple of 8 channels, epilogue bias -> act -> (+res) (no affine, no init), out / res 8-byte aligned.
+ * Weights: w[Cout][Cin][3][3] -> G g G^T in fp64, rounded once, packed per (64-channel tile, 8-channel chunk) as the
+ * kernel's LDS image.  Deterministic and batch-invariant (fixed tile grid, ordered fmaf chains). */
+size_t dcvic_wino_packed_bytes(int Cin, int Cout);
+int dcvic_wino_pack_f32(const float* w, float* packed, int Cin, int Cout, void* stream);
+int dcvic_conv3x3_wino_f32(int Cin, int Cout, const float* packed, const dcvic_conv_io* io, void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * Batched strided GEMM  C[b][m][n] = alpha * sum_k A[b][m][k] * B[b][k][n]
  * Replaces torch.bmm in ldm AttnBlock (model.py:186-196).  Element strides; k ascending.
