@@ -32,6 +32,7 @@ class _Packed(nn.Module):
         if self._plan is None or self._plan_key != k:
             self._plan = self._build_plan()
             self._plan_key = k
+        self._plan.wino = bool(getattr(self, "wino", False))
         return self._plan
 
     def _build_plan(self):
@@ -51,6 +52,7 @@ class Conv2d(_Packed):
         self.in_channels, self.out_channels = in_ch, out_ch
         self.kernel_size, self.stride, self.padding = kernel_size, stride, padding
         self.asym_pad, self.upsample = asym_pad, upsample
+        self.wino = False     # allow_winograd(): set only where no integer decision depends on this layer's exact bits
         self.weight = nn.Parameter(torch.empty(out_ch, in_ch, kernel_size, kernel_size), requires_grad=False)
         self.bias = nn.Parameter(torch.empty(out_ch), requires_grad=False) if bias else None
         nn.init.kaiming_uniform_(self.weight, a=math.sqrt(5))
@@ -70,6 +72,18 @@ class Conv2d(_Packed):
             H, W = src0.shape[2:]
             out_hw = ((H + 1 - self.kernel_size) // self.stride + 1, (W + 1 - self.kernel_size) // self.stride + 1)
         return plan(x, out=out, act=act, res=res, affine=affine, out_hw=out_hw)
+
+
+def allow_winograd(module: nn.Module, on: bool = True) -> nn.Module:
+    """Let every Conv2d(k3, s1, p1) under `module` run as Winograd F(2x2, 3x3) (csrc/wino.hip) when the launch is eligible.
+
+    Winograd re-associates the sum (1e-6 relative against the direct fmaf chain), so this is called ONLY for the frozen VQGAN
+    decoder and the SFT fusion blocks -- the layers after the path's last integer decision (the estimator argmax); the
+    encoder side, hyperprior, CHARM, the ELIC decoder taps and the estimator keep the layer-defined reduction order."""
+    for m in module.modules():
+        if isinstance(m, Conv2d) and m.kernel_size == 3 and m.stride == 1 and m.padding == 1 and not m.asym_pad and not m.upsample:
+            m.wino = on
+    return module
 
 
 class ConvTranspose2d(_Packed):

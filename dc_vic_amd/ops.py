@@ -121,7 +121,7 @@ def shape_stats_report() -> str:
 # ------------------------------------------------------------------------------------------- conv
 # Winograd F(2x2,3x3) for the layers that opted in (ConvPlan.wino): DCVIC_WINO=0 keeps every layer on the direct kernels
 WINO_ENABLED = os.environ.get("DCVIC_WINO", "1") != "0"
-WINO_MIN_BLOCKS = int(os.environ.get("DCVIC_WINO_MIN_BLOCKS", "192"))
+WINO_MIN_BLOCKS = int(os.environ.get("DCVIC_WINO_MIN_BLOCKS", "16"))   # workgroups PER IMAGE below which the direct kernels run
 
 
 class ConvPlan:
@@ -130,6 +130,9 @@ class ConvPlan:
     kind 'conv'  : Conv2d(k, stride, padding given as (pad_t, pad_l)), optional nearest-x2 input
     kind 'convT' : ConvTranspose2d(k=5,s=2,p=2,op=1) (four output phases) or (k=3,s=1,p=1)
     """
+
+    wino = False          # set by the owner: Winograd F(2x2,3x3) allowed (no integer decision downstream of this layer)
+    _wino_pack = None
 
     def __init__(self, weight: Tensor, bias: Optional[Tensor], kind: str = "conv", stride: int = 1,
                  pad: Tuple[int, int] = (0, 0), upsample: bool = False):
@@ -143,8 +146,6 @@ class ConvPlan:
             w = w.view(w.shape[0], w.shape[1], 1, 1)
         self._w = w
         self.phases: List[list] = []      # [desc, {tile class: packed weights}, py, px]
-        self.wino = False                 # set by the owner: Winograd F(2x2,3x3) allowed (no integer decision downstream)
-        self._wino_pack = None
         self.ups_phases = False
         if kind == "conv" and upsample and tuple(w.shape[2:]) == (3, 3) and pad == (1, 1) and stride == 1 \
                 and os.environ.get("DCVIC_UPS_PHASES", "1") != "0":
@@ -208,15 +209,18 @@ class ConvPlan:
         return self
 
     def _wino_ok(self, srcs, N: int, H: int, W: int) -> bool:
-        """Winograd eligibility: Conv2d(k3, s1, p1), 8-channel-aligned sources, even width, and a grid that fills the chip
-        (64 channels x 8 x 32 pixels per workgroup, one workgroup per CU)."""
+        """Winograd eligibility: Conv2d(k3, s1, p1), 8-channel-aligned sources, even width, and a map that fills its
+        64-channel x 8 x 32-pixel workgroup tiles.  A function of the LAYER and the IMAGE size only, never of N: a
+        reconstruction must not depend on the batch it was decoded in."""
         if self.kind != "conv" or self.upsample or self.ups_phases or self.stride != 1 or self.pad != (1, 1) \
                 or (self.KH, self.KW) != (3, 3) or self._w is None:
             return False
         if (W & 1) or self.Cout < 48 or any(s.shape[1] % 8 for s in srcs):
             return False
-        blocks = N * ((H + 7) // 8) * ((W + 31) // 32) * ((self.Cout + 63) // 64)
-        return blocks >= WINO_MIN_BLOCKS
+        ty, tx = (H + 7) // 8, (W + 31) // 32
+        if H * W < 0.6 * (ty * 8 * tx * 32):
+            return False
+        return ty * tx * ((self.Cout + 63) // 64) >= WINO_MIN_BLOCKS
 
     @staticmethod
     def _pack(d: ConvDesc, w: Tensor) -> Tensor:
@@ -285,7 +289,7 @@ class ConvPlan:
             if sc.shape[0] not in (1, N):
                 raise ValueError("conv affine batch must be 1 or N")
         st = _stream()
-        if self.wino and WINO_ENABLED and init is None and affine is None and self._wino_ok(srcs, N, H, W):
+        if self.wino and WINO_ENABLED and init is None and affine is None and (self.wino == "force" or self._wino_ok(srcs, N, H, W)):
             if self._wino_pack is None:
                 nbytes = lib().dcvic_wino_packed_bytes(self.Cin, self.Cout)
                 self._wino_pack = torch.empty(nbytes // 4, dtype=torch.float32, device=self._w.device)

@@ -14,12 +14,11 @@ def run(Cin, Cout, H, W, N, reps=5, res=False, act=0, check=True, srcs_split=Non
     b = torch.randn(Cout, generator=g).to(dev)
     r = torch.randn((N, Cout, H, W), generator=g).to(dev) if res else None
     direct = ops.ConvPlan(w, b, "conv", pad=(1, 1))
-    wino = ops.ConvPlan(w, b, "conv", pad=(1, 1)); wino.wino = True
+    wino = ops.ConvPlan(w, b, "conv", pad=(1, 1)); wino.wino = "force"
     srcs = x if srcs_split is None else list(torch.split(x, srcs_split, dim=1))
     if srcs_split is not None:
         srcs = [s.contiguous() for s in srcs]
     yd = direct(srcs, act=act, res=r)
-    ops.WINO_MIN_BLOCKS = 0
     yw = wino(srcs, act=act, res=r)
     torch.cuda.synchronize()
     msg = f"{Cin}->{Cout} {H}x{W} N={N} res={int(res)} act={act}:"
