@@ -26,6 +26,8 @@
 #include "conv_common.h"
 
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 __device__ float dcvic_wino_zero[16];   // zero-initialised: source of padded lanes
 
@@ -123,21 +125,6 @@ __global__ __launch_bounds__(WN_THREADS, 2) void conv3x3_wino_kernel(const ConvK
     x_rebase(0);
     const int n_stages = K.n_chunks;
     int x_next = 0;                                               // chunk the pointers stand at
-    auto issue_x = [&](int buf) {
-        float* xb = smem + buf * WN_XS;
-#pragma unroll
-        for (int s = 0; s < WN_XSLOTS; ++s)
-            __builtin_amdgcn_global_load_lds(xp[s], (lds_ptr_t)(xb + wave * 64 + s * WN_THREADS), 4, 0, 0);
-        ++x_next;
-        x_left -= KC;
-        if (x_left > 0) {
-#pragma unroll
-            for (int s = 0; s < WN_XSLOTS; ++s) xp[s] = reinterpret_cast<const float*>(reinterpret_cast<const char*>(xp[s]) + xst[s]);
-        } else if (x_next < n_stages) {
-            x_rebase(x_next * KC);
-        }
-    };
-
     // ---- weight DMA: the stage's 32 KiB slab is already the LDS image; thread moves float4 #(tid + j*512)
     const float* wp4[4];
     {
@@ -145,47 +132,14 @@ __global__ __launch_bounds__(WN_THREADS, 2) void conv3x3_wino_kernel(const ConvK
 #pragma unroll
         for (int j = 0; j < 4; ++j) wp4[j] = wbase + 4 * (tid + j * WN_THREADS);
     }
-    auto issue_u = [&](int buf) {
-        float* ub = smem + WN_OFF_U + buf * WN_US;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            __builtin_amdgcn_global_load_lds(reinterpret_cast<const float4*>(wp4[j]), (lds_ptr_t)(ub + (wave * 64 + j * WN_THREADS) * 4), 16, 0, 0);
-            wp4[j] += WN_US;
-        }
-    };
-
     // ---- input transform: this thread's (channel, tile) of a stage
     //   wave -> (q, kpar, jhalf); lane -> (j16, nt, ksq);  channel 4q + 2ksq + kpar, tile row 2nt + jhalf, tile column j16
     const int t_q = wave >> 2, t_kpar = (wave >> 1) & 1, t_jhalf = wave & 1;
     const int t_j16 = lane & 15, t_nt = (lane >> 4) & 1, t_ksq = lane >> 5;
-    const int t_src = (4 * t_q + 2 * t_ksq + t_kpar) * WN_PLANE + (2 * (2 * t_nt + t_jhalf)) * WN_PW + 2 * t_j16;
-    const int t_dst = ((t_q * 2 + t_kpar) * 32 + t_jhalf * 16 + t_j16) * 4 + t_ksq * 2 + t_nt;
-    auto transform = [&](int xbuf, int vbuf) {
-        const float* xr = smem + xbuf * WN_XS + t_src;
-        float d[4][4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const float2 lo = *reinterpret_cast<const float2*>(xr + r * WN_PW);
-            const float2 hi = *reinterpret_cast<const float2*>(xr + r * WN_PW + 2);
-            d[r][0] = lo.x; d[r][1] = lo.y; d[r][2] = hi.x; d[r][3] = hi.y;
-        }
-        float t[4][4];
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            t[0][c] = d[0][c] - d[2][c];
-            t[1][c] = d[1][c] + d[2][c];
-            t[2][c] = d[2][c] - d[1][c];
-            t[3][c] = d[1][c] - d[3][c];
-        }
-        float* vw = smem + WN_OFF_V + vbuf * WN_VS + t_dst;
-#pragma unroll
-        for (int a = 0; a < 4; ++a) {
-            vw[(4 * a + 0) * 512] = t[a][0] - t[a][2];
-            vw[(4 * a + 1) * 512] = t[a][1] + t[a][2];
-            vw[(4 * a + 2) * 512] = t[a][2] - t[a][1];
-            vw[(4 * a + 3) * 512] = t[a][1] - t[a][3];
-        }
-    };
+    const unsigned t_src = 4u * (unsigned)((4 * t_q + 2 * t_ksq + t_kpar) * WN_PLANE + (2 * (2 * t_nt + t_jhalf)) * WN_PW + 2 * t_j16);
+    const unsigned t_dst = 4u * (unsigned)(WN_OFF_V + ((t_q * 2 + t_kpar) * 32 + t_jhalf * 16 + t_j16) * 4 + t_ksq * 2 + t_nt);
+    const unsigned op_u = 4u * (unsigned)(WN_OFF_U + (2 * wave) * 512 + lane * 4);   // this lane's float4 of the wave's first position
+    const unsigned op_v = 4u * (unsigned)(WN_OFF_V + (2 * wave) * 512 + lane * 4);
 
     f32x16 acc[2][2][2];                                          // [position of the wave][mt][nt]
 #pragma unroll
@@ -197,46 +151,133 @@ __global__ __launch_bounds__(WN_THREADS, 2) void conv3x3_wino_kernel(const ConvK
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[i][j][k][r] = 0.f;
 
-    const int op_off = (2 * wave) * 512 + lane * 4;               // this lane's float4 of the wave's first position
-    auto mfma_stage = [&](int ubuf, int vbuf) {
-        const float* ua = smem + WN_OFF_U + ubuf * WN_US + op_off;
-        const float* va = smem + WN_OFF_V + vbuf * WN_VS + op_off;
-        dcvic_static_for<0, 4>([&](auto g_) {
-            constexpr int g = decltype(g_)::value, pi = g >> 1, q = g & 1;
-            const float4 A = *reinterpret_cast<const float4*>(ua + pi * 512 + q * 256);
-            const float4 B = *reinterpret_cast<const float4*>(va + pi * 512 + q * 256);
-            const float a4[4] = {A.x, A.y, A.z, A.w}, b4[4] = {B.x, B.y, B.z, B.w};
+    // All LDS traffic of the loop is inline asm with hand-placed `s_waitcnt lgkmcnt(0)`: hipcc guards every LDS access it
+    // can see with `s_waitcnt vmcnt(0)` while an LDS-DMA is in flight (it cannot prove the DMA's destination does not alias),
+    // which serialises the stage into "DMA latency + transform + MFMA" (measured: 52 % -> MFMA-busy).  Nothing below is
+    // visible to it as an LDS access, so the only vmcnt wait is the explicit one in front of the stage barrier.
+#define WN_FENCE() __builtin_amdgcn_sched_barrier(0)
+#define WN_WAIT_LDS() do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); WN_FENCE(); } while (0)
+    float td[4][4];                                               // raw 4x4 patch of the transform
+    auto t_load = [&](auto r_, unsigned xaddr) {                  // row r of the patch: two ds_read_b64
+        constexpr int r = decltype(r_)::value;
+        f32x2 lo, hi;
+        asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(lo) : "v"(xaddr), "n"(4 * r * WN_PW));
+        asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(hi) : "v"(xaddr), "n"(4 * r * WN_PW + 8));
+        td[r][0] = lo[0]; td[r][1] = lo[1]; td[r][2] = hi[0]; td[r][3] = hi[1];
+    };
+    float tv[16];
+    auto t_compute = [&](auto c_) {                               // column c of B^T d, then nothing else: rows are finished in t_rows
+        constexpr int c = decltype(c_)::value;
+        const float d0 = td[0][c], d1 = td[1][c], d2 = td[2][c], d3 = td[3][c];
+        td[0][c] = d0 - d2; td[1][c] = d1 + d2; td[2][c] = d2 - d1; td[3][c] = d1 - d3;
+    };
+    auto t_rows = [&](auto a_) {                                  // row a of (B^T d) B
+        constexpr int a = decltype(a_)::value;
+        tv[4 * a + 0] = td[a][0] - td[a][2];
+        tv[4 * a + 1] = td[a][1] + td[a][2];
+        tv[4 * a + 2] = td[a][2] - td[a][1];
+        tv[4 * a + 3] = td[a][1] - td[a][3];
+    };
+    auto t_store = [&](auto p_, unsigned vaddr) {
+        constexpr int p = decltype(p_)::value;
+        const float val = tv[p];                                  // (asm operands inside a generic lambda do not capture)
+        asm volatile("ds_write_b32 %0, %1 offset:%2" :: "v"(vaddr), "v"(val), "n"(4 * 512 * p) : "memory");
+    };
+    f32x4 opA[2], opB[2];                                         // operand sets, ping-pong by group parity
+    auto op_load = [&](auto g_, unsigned ua, unsigned va) {
+        constexpr int g = decltype(g_)::value, pi = g >> 1, q = g & 1;
+        f32x4 &ra = opA[g & 1], &rb = opB[g & 1];
+        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(ra) : "v"(ua), "n"(4 * (pi * 512 + q * 256)));
+        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(rb) : "v"(va), "n"(4 * (pi * 512 + q * 256)));
+    };
+    auto dma_x = [&](auto s_, int buf) {
+        constexpr int sl = decltype(s_)::value;
+        __builtin_amdgcn_global_load_lds(xp[sl], (lds_ptr_t)(smem + buf * WN_XS + wave * 64 + sl * WN_THREADS), 4, 0, 0);
+    };
+    auto dma_u = [&](auto j_, int buf) {
+        constexpr int j = decltype(j_)::value;
+        __builtin_amdgcn_global_load_lds(reinterpret_cast<const float4*>(wp4[j]), (lds_ptr_t)(smem + WN_OFF_U + buf * WN_US + (wave * 64 + j * WN_THREADS) * 4), 16, 0, 0);
+    };
+    auto x_advance = [&]() {
+        ++x_next;
+        x_left -= KC;
+        if (x_left > 0) {
 #pragma unroll
-            for (int ksq = 0; ksq < 2; ++ksq)
+            for (int sl = 0; sl < WN_XSLOTS; ++sl) xp[sl] = reinterpret_cast<const float*>(reinterpret_cast<const char*>(xp[sl]) + xst[sl]);
+        } else if (x_next < n_stages) {
+            x_rebase(x_next * KC);
+        }
+    };
+    auto u_advance = [&]() {
 #pragma unroll
-                for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-                    for (int nt = 0; nt < 2; ++nt)
-                        acc[pi][mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[ksq * 2 + mt], b4[ksq * 2 + nt], acc[pi][mt][nt], 0, 0, 0);
-        });
+        for (int j = 0; j < 4; ++j) wp4[j] += WN_US;
     };
 
     // ---- pipeline
     float* const sbias = smem + WN_OFF_BIAS;
     if (tid < WN_CO) sbias[tid] = K.bias ? K.bias[min(cotile * WN_CO + tid, K.Cout - 1)] : 0.f;
-    issue_x(0);
-    issue_u(0);
-    if (n_stages > 1) issue_x(1);
+    dcvic_static_for<0, WN_XSLOTS>([&](auto s_) { dma_x(s_, 0); });
+    x_advance();
+    dcvic_static_for<0, 4>([&](auto j_) { dma_u(j_, 0); });
+    u_advance();
+    if (n_stages > 1) {
+        dcvic_static_for<0, WN_XSLOTS>([&](auto s_) { dma_x(s_, 1); });
+        x_advance();
+    }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    transform(0, 0);
+    WN_FENCE();
+    dcvic_static_for<0, 4>([&](auto r_) { t_load(r_, t_src); });
+    WN_WAIT_LDS();
+    dcvic_static_for<0, 4>([&](auto c_) { t_compute(c_); });
+    dcvic_static_for<0, 4>([&](auto a_) { t_rows(a_); });
+    dcvic_static_for<0, 16>([&](auto p_) { t_store(p_, t_dst); });
+    WN_WAIT_LDS();
     __syncthreads();
-    for (int s = 0; s < n_stages; ++s) {
+    WN_FENCE();
+    // more1 / more2: a stage s + 1 / s + 2 exists (compile-time: no branches between the MFMAs)
+    auto run_stage = [&](auto more1_, auto more2_, int s) {
+        constexpr bool more1 = decltype(more1_)::value, more2 = decltype(more2_)::value;
         const int cur = s & 1, nxt = cur ^ 1;
-        if (s + 2 < n_stages) issue_x(cur);                       // X(s+2) over X(s), transformed during stage s-1
-        if (s + 1 < n_stages) {
-            issue_u(nxt);
-            transform(nxt, nxt);                                  // X(s+1) -> V(s+1)
-        }
-        mfma_stage(cur, cur);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned ua = op_u + (unsigned)(cur * WN_US * 4), va = op_v + (unsigned)(cur * WN_VS * 4);
+        const unsigned xaddr = t_src + (unsigned)(nxt * WN_XS * 4), vaddr = t_dst + (unsigned)(nxt * WN_VS * 4);
+        op_load(std::integral_constant<int, 0>{}, ua, va);
+        WN_WAIT_LDS();
+        // 32 MFMA slots; slot k = group g (position pi = g/2, k-quad q = g%2) x (ksq, mt, nt).  After each MFMA one or two
+        // "filler" instructions of the stage's other work issue in its shadow: operand reads of the next group, the DMA of
+        // X(s+2) and U(s+1), the transform of X(s+1) into V(s+1).
+        dcvic_static_for<0, 32>([&](auto k_) {
+            constexpr int k = decltype(k_)::value, g = k >> 3, i = k & 7, pi = g >> 1, ksq = i >> 2, mt = (i >> 1) & 1, nt = i & 1;
+            acc[pi][mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(opA[g & 1][ksq * 2 + mt], opB[g & 1][ksq * 2 + nt], acc[pi][mt][nt], 0, 0, 0);
+            WN_FENCE();
+            if constexpr (i == 0 && g < 3) op_load(std::integral_constant<int, g + 1>{}, ua, va);
+            if constexpr (g == 0 && i >= 1 && i <= 6) { if constexpr (more2) dma_x(std::integral_constant<int, i - 1>{}, cur); }
+            if constexpr (g == 0 && i == 7) { if constexpr (more1) { dma_u(std::integral_constant<int, 0>{}, nxt); dma_u(std::integral_constant<int, 1>{}, nxt); } }
+            if constexpr (g == 1 && i == 1) { if constexpr (more1) { dma_u(std::integral_constant<int, 2>{}, nxt); dma_u(std::integral_constant<int, 3>{}, nxt); } }
+            if constexpr (g == 1 && i >= 2 && i <= 5) { if constexpr (more1) t_load(std::integral_constant<int, i - 2>{}, xaddr); }
+            if constexpr (g == 2 && i >= 1 && i <= 4) { if constexpr (more1) t_compute(std::integral_constant<int, i - 1>{}); }
+            if constexpr (g == 2 && i >= 5) { if constexpr (more1) t_rows(std::integral_constant<int, i - 5>{}); }
+            if constexpr (g == 3 && i == 0) { if constexpr (more1) t_rows(std::integral_constant<int, 3>{}); }
+            if constexpr (g == 3 && i >= 1 && i <= 4) {
+                if constexpr (more1) dcvic_static_for<0, 4>([&](auto w_) { t_store(std::integral_constant<int, 4 * (i - 1) + decltype(w_)::value>{}, vaddr); });
+            }
+            if constexpr (i == 7 && g < 3) WN_WAIT_LDS();        // operands of group g + 1 (and everything issued before) have landed
+            WN_FENCE();
+        });
+        if constexpr (more2) x_advance();
+        if constexpr (more1) u_advance();
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         __syncthreads();
+        WN_FENCE();
+    };
+    {
+        int s = 0;
+        for (; s + 2 < n_stages; ++s) run_stage(std::true_type{}, std::true_type{}, s);
+        if (s + 1 < n_stages) { run_stage(std::true_type{}, std::false_type{}, s); ++s; }
+        run_stage(std::false_type{}, std::false_type{}, s);
     }
+#undef WN_FENCE
+#undef WN_WAIT_LDS
 
     // ---- epilogue: exchange through LDS, A^T M A, bias -> act -> (+res) -> store
     float* const E = smem;                                        // [16 positions][32 co][64 tiles]
