@@ -14,12 +14,12 @@
 //     exact LDS image) arrive by LDS-DMA (`global_load_lds_dword / _dwordx4`), two stages / one stage ahead;
 //   * every thread transforms ONE (channel, tile) 4x4 patch per stage (8 ds_read_b64, 32 adds, 16 ds_write_b32) into the
 //     V image of the NEXT stage while the MFMAs of the current stage run;
-//   * wave w owns Winograd positions 2w and 2w+1: per position a 64 x 64 (co x tile) GEMM block as 2 x 2
-//     `v_mfma_f32_32x32x2_f32` accumulators (128 accumulator registers per lane).  The U and V images are laid out so that
-//     ONE ds_read_b128 per operand feeds two k-steps x two 32-blocks (8 MFMAs): word ((q*2 + kpar)*32 + m)*4 + ksq*2 + blk
-//     of a position's 512-word slab holds channel 4q + 2ksq + kpar, row/column blk*32 + m;
-//   * epilogue: the 16 positions of a (co, tile) pair live in 8 different waves -> exchanged through LDS in two rounds of
-//     32 output channels (128 KiB, the staging buffers are dead by then), A^T M A, bias -> act -> (+res) -> float2 stores.
+//   * wave w = (co group cg = w % 4 of 16 channels, tile half th = w / 4 of 32 tiles) owns ALL 16 Winograd positions of its
+//     16 x 32 block: per position two `v_mfma_f32_16x16x4_f32` accumulators (128 accumulator registers per lane), fed by
+//     ONE ds_read_b64 (U: both k-steps) and ONE ds_read_b128 (V: two 16-tile blocks x both k-steps) per position --
+//     U slab word ((cg*4 + k)*16 + m)*2 + ks, V slab word ((th*4 + k)*16 + n)*4 + blk*2 + ks hold channel 4ks + k;
+//   * since a lane then holds the same (co, tile) element of all 16 positions, the output transform A^T M A runs in
+//     registers: no LDS exchange and no barrier after the last stage; bias -> act -> (+res) -> float2 stores.
 // LDS: 2 x 12 KiB raw patch + 2 x 32 KiB U + 2 x 32 KiB V + bias row = 152.25 KiB: one workgroup per CU.
 // Deterministic and batch-invariant: per position the reduction runs over chunks ascending, then k-steps ascending inside
 // the MFMA's ordered fmaf chain; the tiling never depends on N.
@@ -44,7 +44,7 @@ __device__ float dcvic_wino_zero[16];   // zero-initialised: source of padded la
 #define WN_OFF_U (2 * WN_XS)
 #define WN_OFF_V (WN_OFF_U + 2 * WN_US)
 #define WN_OFF_BIAS (WN_OFF_V + 2 * WN_VS)
-#define WN_LDS_FLOATS (WN_OFF_BIAS + WN_CO)
+#define WN_LDS_FLOATS (WN_OFF_BIAS + 2 * WN_CO)
 
 // U = G g G^T of one (co, ci) 3x3 kernel, position p = 4a + b
 __device__ __forceinline__ double wino_u(const float* g, int a, int b) {
@@ -57,20 +57,19 @@ __device__ __forceinline__ double wino_u(const float* g, int a, int b) {
     return s;
 }
 
-// packed[cotile][chunk][p 16][q 2][kpar 2][m 32][ksq 2][mt 2]  <-  w[Cout][Cin][3][3]   (fp64 transform, rounded once)
+// packed[cotile][chunk][p 16][cg 4][k 4][m 16][ks 2]  <-  w[Cout][Cin][3][3]   (fp64 transform, rounded once)
 __global__ void wino_pack_kernel(const float* __restrict__ w, float* __restrict__ wp, int Cin, int Cout, int n_chunks, long long total) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= total) return;
     long long r = i;
-    const int mt = r & 1; r >>= 1;
-    const int ksq = r & 1; r >>= 1;
-    const int m = r & 31; r >>= 5;
-    const int kpar = r & 1; r >>= 1;
-    const int q = r & 1; r >>= 1;
+    const int ks = r & 1; r >>= 1;
+    const int m = r & 15; r >>= 4;
+    const int k = r & 3; r >>= 2;
+    const int cg = r & 3; r >>= 2;
     const int p = r & 15; r >>= 4;
     const int chunk = (int)(r % n_chunks);
     const int cotile = (int)(r / n_chunks);
-    const int co = cotile * WN_CO + mt * 32 + m, ci = chunk * KC + 4 * q + 2 * ksq + kpar;
+    const int co = cotile * WN_CO + cg * 16 + m, ci = chunk * KC + 4 * ks + k;
     float v = 0.f;
     if (co < Cout && ci < Cin) v = (float)wino_u(w + ((long long)co * Cin + ci) * 9, p >> 2, p & 3);
     wp[i] = v;
@@ -82,74 +81,92 @@ __global__ __launch_bounds__(WN_THREADS, 2) void conv3x3_wino_kernel(const ConvK
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // 0..7
 
-    int b;
-    {
-        const int orig = blockIdx.x, nb = K.nblocks;
-        const int q = nb / NXCD, r = nb % NXCD, x = orig % NXCD;
-        b = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + orig / NXCD;
-    }
-    const int cotile = b % K.n_cotiles; b /= K.n_cotiles;
-    const int tile_x = b % K.tiles_x; b /= K.tiles_x;
-    const int tile_y = b % K.tiles_y; b /= K.tiles_y;
-    const int n = b;
-    const int oy0 = tile_y * WN_TH, ox0 = tile_x * WN_TW;
-    const int iy0 = oy0 - 1, ix0 = ox0 - 1;
     const long long HW = (long long)K.H * K.W;
+    const int S = K.n_chunks;                                     // stages (8-channel chunks) per tile
 
-    // ---- raw-patch DMA slots: element e = tid + s*512 of [8 ch][10][34]; running pointers advanced per stage
+    // ---- PERSISTENT workgroup: XCD x = blockIdx.x % 8 owns the contiguous range [xs, xe) of tile indices (cotile fastest, so
+    // the workgroups of one L2 share input patches and weight slabs); slot j = blockIdx.x / 8 takes tiles xs + j, xs + j + J, ...
+    // All stages of all its tiles form ONE stream: the DMA of the next tile's first stages is in flight during the last stages
+    // and the (register-only) epilogue of the current tile, so nothing drains at a tile boundary.
+    int xe;
+    const int J = (int)gridDim.x / NXCD;
+    int first;
+    {
+        const int nb = K.nblocks, q = nb / NXCD, r = nb % NXCD, x = (int)blockIdx.x % NXCD;
+        const int xs = x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q;
+        xe = xs + (x < r ? q + 1 : q);
+        first = xs + (int)blockIdx.x / NXCD;
+    }
+    if (first >= xe) return;                                      // (uniform: the whole workgroup leaves before any barrier)
+    const int ntile = (xe - first + J - 1) / J;
+    const int total = ntile * S;
+    auto decode = [&](int b, int& cotile, int& n, int& oy0, int& ox0) __attribute__((always_inline)) {
+        cotile = b % K.n_cotiles; b /= K.n_cotiles;
+        const int tile_x = b % K.tiles_x; b /= K.tiles_x;
+        const int tile_y = b % K.tiles_y; b /= K.tiles_y;
+        n = b; oy0 = tile_y * WN_TH; ox0 = tile_x * WN_TW;
+    };
+
+    // ---- raw-patch DMA: element e = tid + s*512 of [8 ch][10][34]; running pointers, advanced per stage, re-derived per tile
     const float* xp[WN_XSLOTS];
     unsigned xst[WN_XSLOTS];
     int poff[WN_XSLOTS];
-#pragma unroll
-    for (int s = 0; s < WN_XSLOTS; ++s) {
-        const int e = tid + s * WN_THREADS;
-        int o = -1;
-        if (e < KC * WN_PLANE) {
-            const int k = e / WN_PLANE, r = e - k * WN_PLANE;
-            const int py = r / WN_PW, px = r - py * WN_PW;
-            const int iy = iy0 + py, ix = ix0 + px;
-            if (iy >= 0 && iy < K.H && ix >= 0 && ix < K.W) o = (int)(k * HW) + iy * K.W + ix;
-        }
-        poff[s] = o;
-        xst[s] = o >= 0 ? (unsigned)(KC * HW * 4) : 0u;
-    }
-    int x_left = 0;
-    auto x_rebase = [&](int c) {                                  // pointers for absolute input channel c
+    int x_left = 0, x_n = 0, x_b = first, x_next = 0;             // X stream: image, tile index, chunk inside the tile
+    auto x_rebase = [&](int c) __attribute__((always_inline)) {                                  // pointers for absolute input channel c of image x_n
         int si = 0;
         if (c >= K.srcC[0]) { c -= K.srcC[0]; si = 1; if (c >= K.srcC[1]) { c -= K.srcC[1]; si = 2; } }
-        const float* base = K.src[si] + (long long)n * K.src_bs[si] + (long long)c * HW;
+        const float* base = K.src[si] + (long long)x_n * K.src_bs[si] + (long long)c * HW;
 #pragma unroll
         for (int s = 0; s < WN_XSLOTS; ++s) xp[s] = poff[s] >= 0 ? base + poff[s] : dcvic_wino_zero;
         x_left = K.srcC[si] - c;
     };
-    x_rebase(0);
-    const int n_stages = K.n_chunks;
-    int x_next = 0;                                               // chunk the pointers stand at
+    auto x_setup = [&](int b) __attribute__((always_inline)) {
+        int cot, oy0, ox0;
+        decode(b, cot, x_n, oy0, ox0);
+        const int iy0 = oy0 - 1, ix0 = ox0 - 1;
+#pragma unroll
+        for (int s = 0; s < WN_XSLOTS; ++s) {
+            const int e = tid + s * WN_THREADS;
+            int o = -1;
+            if (e < KC * WN_PLANE) {
+                const int k = e / WN_PLANE, r = e - k * WN_PLANE;
+                const int py = r / WN_PW, px = r - py * WN_PW;
+                const int iy = iy0 + py, ix = ix0 + px;
+                if (iy >= 0 && iy < K.H && ix >= 0 && ix < K.W) o = (int)(k * HW) + iy * K.W + ix;
+            }
+            poff[s] = o;
+            xst[s] = o >= 0 ? (unsigned)(KC * HW * 4) : 0u;
+        }
+        x_rebase(0);
+    };
+    x_setup(first);
     // ---- weight DMA: the stage's 32 KiB slab is already the LDS image; thread moves float4 #(tid + j*512)
     const float* wp4[4];
-    {
-        const float* wbase = K.wp + (long long)cotile * K.n_chunks * (long long)WN_US;
+    int u_b = first, u_next = 0;                                  // U stream
+    auto u_setup = [&](int b) __attribute__((always_inline)) {
+        const float* wbase = K.wp + (long long)(b % K.n_cotiles) * S * (long long)WN_US;
 #pragma unroll
         for (int j = 0; j < 4; ++j) wp4[j] = wbase + 4 * (tid + j * WN_THREADS);
-    }
+    };
+    u_setup(first);
     // ---- input transform: this thread's (channel, tile) of a stage
-    //   wave -> (q, kpar, jhalf); lane -> (j16, nt, ksq);  channel 4q + 2ksq + kpar, tile row 2nt + jhalf, tile column j16
-    const int t_q = wave >> 2, t_kpar = (wave >> 1) & 1, t_jhalf = wave & 1;
-    const int t_j16 = lane & 15, t_nt = (lane >> 4) & 1, t_ksq = lane >> 5;
-    const unsigned t_src = 4u * (unsigned)((4 * t_q + 2 * t_ksq + t_kpar) * WN_PLANE + (2 * (2 * t_nt + t_jhalf)) * WN_PW + 2 * t_j16);
-    const unsigned t_dst = 4u * (unsigned)(WN_OFF_V + ((t_q * 2 + t_kpar) * 32 + t_jhalf * 16 + t_j16) * 4 + t_ksq * 2 + t_nt);
-    const unsigned op_u = 4u * (unsigned)(WN_OFF_U + (2 * wave) * 512 + lane * 4);   // this lane's float4 of the wave's first position
-    const unsigned op_v = 4u * (unsigned)(WN_OFF_V + (2 * wave) * 512 + lane * 4);
+    //   wave -> (th, k); lane -> (n, blk, ks);  channel 4ks + k, tile row 2th + blk, tile column n
+    const int t_th = wave >> 2, t_k = wave & 3;
+    const int t_n = lane & 15, t_blk = (lane >> 4) & 1, t_ks = lane >> 5;
+    const unsigned t_src = 4u * (unsigned)((4 * t_ks + t_k) * WN_PLANE + (2 * (2 * t_th + t_blk)) * WN_PW + 2 * t_n);
+    const unsigned t_dst = 4u * (unsigned)(WN_OFF_V + ((t_th * 4 + t_k) * 16 + t_n) * 4 + t_blk * 2 + t_ks);
+    // ---- MFMA operands: wave -> (cg = co group, th = tile half)
+    const int cg = wave & 3, th = wave >> 2;
+    const unsigned op_u = 4u * (unsigned)(WN_OFF_U + cg * 128 + lane * 2);   // this lane's float2 of position 0
+    const unsigned op_v = 4u * (unsigned)(WN_OFF_V + th * 256 + lane * 4);   // this lane's float4 of position 0
 
-    f32x16 acc[2][2][2];                                          // [position of the wave][mt][nt]
+    f32x4 acc[16][2];                                             // [position][16-tile block]
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < 16; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
-            for (int k = 0; k < 2; ++k)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[i][j][k][r] = 0.f;
+            for (int r = 0; r < 4; ++r) acc[i][j][r] = 0.f;
 
     // All LDS traffic of the loop is inline asm with hand-placed `s_waitcnt lgkmcnt(0)`: hipcc guards every LDS access it
     // can see with `s_waitcnt vmcnt(0)` while an LDS-DMA is in flight (it cannot prove the DMA's destination does not alias),
@@ -183,12 +200,14 @@ __global__ __launch_bounds__(WN_THREADS, 2) void conv3x3_wino_kernel(const ConvK
         const float val = tv[p];                                  // (asm operands inside a generic lambda do not capture)
         asm volatile("ds_write_b32 %0, %1 offset:%2" :: "v"(vaddr), "v"(val), "n"(4 * 512 * p) : "memory");
     };
-    f32x4 opA[2], opB[2];                                         // operand sets, ping-pong by group parity
-    auto op_load = [&](auto g_, unsigned ua, unsigned va) {
-        constexpr int g = decltype(g_)::value, pi = g >> 1, q = g & 1;
-        f32x4 &ra = opA[g & 1], &rb = opB[g & 1];
-        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(ra) : "v"(ua), "n"(4 * (pi * 512 + q * 256)));
-        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(rb) : "v"(va), "n"(4 * (pi * 512 + q * 256)));
+    f32x2 opA[2];                                                 // operand sets, ping-pong by position parity
+    f32x4 opB[2];
+    auto op_load = [&](auto p_, unsigned ua, unsigned va) {
+        constexpr int p = decltype(p_)::value;
+        f32x2& ra = opA[p & 1];
+        f32x4& rb = opB[p & 1];
+        asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(ra) : "v"(ua), "n"(4 * 512 * p));
+        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(rb) : "v"(va), "n"(4 * 512 * p));
     };
     auto dma_x = [&](auto s_, int buf) {
         constexpr int sl = decltype(s_)::value;
@@ -198,29 +217,103 @@ __global__ __launch_bounds__(WN_THREADS, 2) void conv3x3_wino_kernel(const ConvK
         constexpr int j = decltype(j_)::value;
         __builtin_amdgcn_global_load_lds(reinterpret_cast<const float4*>(wp4[j]), (lds_ptr_t)(smem + WN_OFF_U + buf * WN_US + (wave * 64 + j * WN_THREADS) * 4), 16, 0, 0);
     };
-    auto x_advance = [&]() {
-        ++x_next;
-        x_left -= KC;
-        if (x_left > 0) {
+    auto x_advance = [&]() __attribute__((always_inline)) {                                     // after the DMA of an X stage: on to the next stage of the stream
+        if (++x_next == S) {
+            x_next = 0;
+            x_b += J;
+            if (x_b < xe) x_setup(x_b);
+        } else {
+            x_left -= KC;
+            if (x_left > 0) {
 #pragma unroll
-            for (int sl = 0; sl < WN_XSLOTS; ++sl) xp[sl] = reinterpret_cast<const float*>(reinterpret_cast<const char*>(xp[sl]) + xst[sl]);
-        } else if (x_next < n_stages) {
-            x_rebase(x_next * KC);
+                for (int sl = 0; sl < WN_XSLOTS; ++sl) xp[sl] = reinterpret_cast<const float*>(reinterpret_cast<const char*>(xp[sl]) + xst[sl]);
+            } else {
+                x_rebase(x_next * KC);
+            }
         }
     };
-    auto u_advance = [&]() {
+    auto u_advance = [&]() __attribute__((always_inline)) {
+        if (++u_next == S) {
+            u_next = 0;
+            u_b += J;
+            if (u_b < xe) u_setup(u_b);
+        } else {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) wp4[j] += WN_US;
+            for (int j = 0; j < 4; ++j) wp4[j] += WN_US;
+        }
+    };
+
+    // ---- epilogue of one tile, in registers: lane holds element (co = 16cg + 4(lane/16) + r, tile = (row 2th + blk, column
+    // lane%16)) of all 16 positions.  A^T M A, bias -> act -> (+res) -> float2 stores; a block's residuals are requested up front.
+    float* const sbias = smem + WN_OFF_BIAS;                      // [2][64], by tile parity
+    const int tx = lane & 15, lq = lane >> 4;
+    const int act = K.act;
+    const bool has_bias = K.bias != nullptr, has_res = K.res != nullptr;
+    auto tile_epilogue = [&](int cotile, int n, int oy0, int ox0, int par) __attribute__((always_inline)) {
+        const int ox = ox0 + 2 * tx;
+        const bool in_x = ox < K.W;
+        const int co0 = cotile * WN_CO + cg * 16 + 4 * lq;
+        float bv[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) bv[r] = has_bias ? sbias[par * WN_CO + cg * 16 + 4 * lq + r] : 0.f;
+        dcvic_static_for<0, 2>([&](auto blk_) {
+            constexpr int blk = decltype(blk_)::value;
+            const int oy = oy0 + 2 * (2 * th + blk);
+            const bool in_y0 = oy < K.H, in_y1 = oy + 1 < K.H;
+            const long long pix = (long long)oy * K.W + ox;
+            float* const ob = K.out + (long long)n * K.out_bs + pix;
+            const float* const rb = has_res ? K.res + (long long)n * K.res_bs + pix : nullptr;
+            f32x2 r0[4], r1[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                r0[r] = f32x2{0.f, 0.f}; r1[r] = f32x2{0.f, 0.f};
+                const int co = co0 + r;
+                if (has_res && in_x && co < K.Cout) {
+                    if (in_y0) r0[r] = *reinterpret_cast<const f32x2*>(rb + (long long)co * HW);
+                    if (in_y1) r1[r] = *reinterpret_cast<const f32x2*>(rb + (long long)co * HW + K.W);
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float s0[4], s1[4];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    s0[c] = acc[c][blk][r] + acc[4 + c][blk][r] + acc[8 + c][blk][r];
+                    s1[c] = acc[4 + c][blk][r] - acc[8 + c][blk][r] - acc[12 + c][blk][r];
+                }
+                float y00 = s0[0] + s0[1] + s0[2], y01 = s0[1] - s0[2] - s0[3];
+                float y10 = s1[0] + s1[1] + s1[2], y11 = s1[1] - s1[2] - s1[3];
+                const int co = co0 + r;
+                if (co < K.Cout && in_x) {
+                    y00 += bv[r]; y01 += bv[r]; y10 += bv[r]; y11 += bv[r];
+                    y00 = dcvic_act(y00, act); y01 = dcvic_act(y01, act); y10 = dcvic_act(y10, act); y11 = dcvic_act(y11, act);
+                    const long long co_off = (long long)co * HW;
+                    if (in_y0) *reinterpret_cast<f32x2*>(ob + co_off) = f32x2{y00 + r0[r][0], y01 + r0[r][1]};
+                    if (in_y1) *reinterpret_cast<f32x2*>(ob + co_off + K.W) = f32x2{y10 + r1[r][0], y11 + r1[r][1]};
+                }
+            }
+        });
+#pragma unroll
+        for (int i = 0; i < 16; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[i][j][r] = 0.f;
+    };
+    auto stage_bias = [&](int b, int par) __attribute__((always_inline)) {                       // bias row of tile b -> sbias[par] (read >= one barrier later)
+        if (tid < WN_CO) sbias[par * WN_CO + tid] = has_bias ? K.bias[min((b % K.n_cotiles) * WN_CO + tid, K.Cout - 1)] : 0.f;
     };
 
     // ---- pipeline
-    float* const sbias = smem + WN_OFF_BIAS;
-    if (tid < WN_CO) sbias[tid] = K.bias ? K.bias[min(cotile * WN_CO + tid, K.Cout - 1)] : 0.f;
+    int c_b = first, c_chunk = 0, c_par = 0;                      // compute stream: tile, chunk inside it, tile parity
+    int c_cotile, c_n, c_oy0, c_ox0;
+    decode(first, c_cotile, c_n, c_oy0, c_ox0);
+    stage_bias(first, 0);
     dcvic_static_for<0, WN_XSLOTS>([&](auto s_) { dma_x(s_, 0); });
     x_advance();
     dcvic_static_for<0, 4>([&](auto j_) { dma_u(j_, 0); });
     u_advance();
-    if (n_stages > 1) {
+    if (total > 1) {
         dcvic_static_for<0, WN_XSLOTS>([&](auto s_) { dma_x(s_, 1); });
         x_advance();
     }
@@ -235,102 +328,58 @@ __global__ __launch_bounds__(WN_THREADS, 2) void conv3x3_wino_kernel(const ConvK
     WN_WAIT_LDS();
     __syncthreads();
     WN_FENCE();
-    // more1 / more2: a stage s + 1 / s + 2 exists (compile-time: no branches between the MFMAs)
-    auto run_stage = [&](auto more1_, auto more2_, int s) {
+    // more1 / more2: a stage g + 1 / g + 2 exists in the stream (compile-time: no branches between the MFMAs)
+    auto run_stage = [&](auto more1_, auto more2_, int g) __attribute__((always_inline)) {
         constexpr bool more1 = decltype(more1_)::value, more2 = decltype(more2_)::value;
-        const int cur = s & 1, nxt = cur ^ 1;
+        const int cur = g & 1, nxt = cur ^ 1;
         const unsigned ua = op_u + (unsigned)(cur * WN_US * 4), va = op_v + (unsigned)(cur * WN_VS * 4);
         const unsigned xaddr = t_src + (unsigned)(nxt * WN_XS * 4), vaddr = t_dst + (unsigned)(nxt * WN_VS * 4);
         op_load(std::integral_constant<int, 0>{}, ua, va);
-        WN_WAIT_LDS();
-        // 32 MFMA slots; slot k = group g (position pi = g/2, k-quad q = g%2) x (ksq, mt, nt).  After each MFMA one or two
-        // "filler" instructions of the stage's other work issue in its shadow: operand reads of the next group, the DMA of
-        // X(s+2) and U(s+1), the transform of X(s+1) into V(s+1).
-        dcvic_static_for<0, 32>([&](auto k_) {
-            constexpr int k = decltype(k_)::value, g = k >> 3, i = k & 7, pi = g >> 1, ksq = i >> 2, mt = (i >> 1) & 1, nt = i & 1;
-            acc[pi][mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(opA[g & 1][ksq * 2 + mt], opB[g & 1][ksq * 2 + nt], acc[pi][mt][nt], 0, 0, 0);
+        // 64 MFMA slots = 16 positions x (k-step, block).  In front of a position's four MFMAs: wait for its operands, then
+        // request the next position's; behind its MFMAs one piece of the stage's other work issues in their shadow: the
+        // DMA of U(g+1) and X(g+2), the transform of X(g+1) into V(g+1).
+        dcvic_static_for<0, 16>([&](auto p_) {
+            constexpr int pp = decltype(p_)::value;
+            WN_WAIT_LDS();
+            if constexpr (pp < 15) op_load(std::integral_constant<int, pp + 1>{}, ua, va);
             WN_FENCE();
-            if constexpr (i == 0 && g < 3) op_load(std::integral_constant<int, g + 1>{}, ua, va);
-            if constexpr (g == 0 && i >= 1 && i <= 6) { if constexpr (more2) dma_x(std::integral_constant<int, i - 1>{}, cur); }
-            if constexpr (g == 0 && i == 7) { if constexpr (more1) { dma_u(std::integral_constant<int, 0>{}, nxt); dma_u(std::integral_constant<int, 1>{}, nxt); } }
-            if constexpr (g == 1 && i == 1) { if constexpr (more1) { dma_u(std::integral_constant<int, 2>{}, nxt); dma_u(std::integral_constant<int, 3>{}, nxt); } }
-            if constexpr (g == 1 && i >= 2 && i <= 5) { if constexpr (more1) t_load(std::integral_constant<int, i - 2>{}, xaddr); }
-            if constexpr (g == 2 && i >= 1 && i <= 4) { if constexpr (more1) t_compute(std::integral_constant<int, i - 1>{}); }
-            if constexpr (g == 2 && i >= 5) { if constexpr (more1) t_rows(std::integral_constant<int, i - 5>{}); }
-            if constexpr (g == 3 && i == 0) { if constexpr (more1) t_rows(std::integral_constant<int, 3>{}); }
-            if constexpr (g == 3 && i >= 1 && i <= 4) {
-                if constexpr (more1) dcvic_static_for<0, 4>([&](auto w_) { t_store(std::integral_constant<int, 4 * (i - 1) + decltype(w_)::value>{}, vaddr); });
-            }
-            if constexpr (i == 7 && g < 3) WN_WAIT_LDS();        // operands of group g + 1 (and everything issued before) have landed
-            WN_FENCE();
+            dcvic_static_for<0, 4>([&](auto i_) {
+                constexpr int i = decltype(i_)::value, ks = i >> 1, blk = i & 1;
+                acc[pp][blk] = __builtin_amdgcn_mfma_f32_16x16x4f32(opA[pp & 1][ks], opB[pp & 1][blk * 2 + ks], acc[pp][blk], 0, 0, 0);
+                WN_FENCE();
+                if constexpr (more1 && pp < 2 && (i & 1) == 0) dma_u(std::integral_constant<int, 2 * pp + (i >> 1)>{}, nxt);
+                if constexpr (more2 && pp >= 2 && pp < 5 && (i & 1) == 0) dma_x(std::integral_constant<int, 2 * (pp - 2) + (i >> 1)>{}, cur);
+                if constexpr (more1 && pp >= 6 && pp < 8 && (i & 1) == 0) t_load(std::integral_constant<int, 2 * (pp - 6) + (i >> 1)>{}, xaddr);
+                if constexpr (more1 && pp == 9) t_compute(std::integral_constant<int, i>{});
+                if constexpr (more1 && pp == 10) t_rows(std::integral_constant<int, i>{});
+                if constexpr (more1 && pp >= 11 && pp < 15) {
+                    t_store(std::integral_constant<int, 4 * (pp - 11) + i>{}, vaddr);
+                }
+                WN_FENCE();
+            });
         });
         if constexpr (more2) x_advance();
         if constexpr (more1) u_advance();
+        if (++c_chunk == S) {                                     // the tile is complete: write it out, move the compute stream on
+            tile_epilogue(c_cotile, c_n, c_oy0, c_ox0, c_par);
+            c_chunk = 0; c_b += J; c_par ^= 1;
+            if (c_b < xe) {
+                decode(c_b, c_cotile, c_n, c_oy0, c_ox0);
+                stage_bias(c_b, c_par);
+            }
+        }
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         __syncthreads();
         WN_FENCE();
     };
     {
-        int s = 0;
-        for (; s + 2 < n_stages; ++s) run_stage(std::true_type{}, std::true_type{}, s);
-        if (s + 1 < n_stages) { run_stage(std::true_type{}, std::false_type{}, s); ++s; }
-        run_stage(std::false_type{}, std::false_type{}, s);
+        int g = 0;
+        for (; g + 2 < total; ++g) run_stage(std::true_type{}, std::true_type{}, g);
+        if (g + 1 < total) { run_stage(std::true_type{}, std::false_type{}, g); ++g; }
+        run_stage(std::false_type{}, std::false_type{}, g);
     }
 #undef WN_FENCE
 #undef WN_WAIT_LDS
-
-    // ---- epilogue: exchange through LDS, A^T M A, bias -> act -> (+res) -> store
-    float* const E = smem;                                        // [16 positions][32 co][64 tiles]
-    const int lane_j = lane & 31, lane_k = lane >> 5;
-    const int ty = lane >> 4, tx = lane & 15;
-    const int oy = oy0 + 2 * ty, ox = ox0 + 2 * tx;
-    const bool in_x = ox < K.W, in_y0 = oy < K.H, in_y1 = oy + 1 < K.H;
-    const long long pix = (long long)oy * K.W + ox;
-    float* const ob = K.out + (long long)n * K.out_bs + pix;
-    const float* const rb = K.res ? K.res + (long long)n * K.res_bs + pix : nullptr;
-    const int act = K.act;
-    const bool has_bias = K.bias != nullptr;
-    dcvic_static_for<0, 2>([&](auto h_) {
-        constexpr int h = decltype(h_)::value;
-        if (h) __syncthreads();
-#pragma unroll
-        for (int pi = 0; pi < 2; ++pi)
-#pragma unroll
-            for (int nt = 0; nt < 2; ++nt)
-#pragma unroll
-                for (int r = 0; r < 16; ++r)
-                    E[((2 * wave + pi) * 32 + 8 * (r >> 2) + 4 * lane_k + (r & 3)) * 64 + nt * 32 + lane_j] = acc[pi][h][nt][r];
-        __syncthreads();
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int col = wave * 4 + i;                          // channel inside this round's 32
-            float m[16];
-#pragma unroll
-            for (int p = 0; p < 16; ++p) m[p] = E[(p * 32 + col) * 64 + lane];
-            float s0[4], s1[4];
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                s0[c] = m[c] + m[4 + c] + m[8 + c];
-                s1[c] = m[4 + c] - m[8 + c] - m[12 + c];
-            }
-            float y00 = s0[0] + s0[1] + s0[2], y01 = s0[1] - s0[2] - s0[3];
-            float y10 = s1[0] + s1[1] + s1[2], y11 = s1[1] - s1[2] - s1[3];
-            const int co = cotile * WN_CO + h * 32 + col;
-            if (co < K.Cout && in_x) {
-                if (has_bias) { const float bv = sbias[h * 32 + col]; y00 += bv; y01 += bv; y10 += bv; y11 += bv; }
-                y00 = dcvic_act(y00, act); y01 = dcvic_act(y01, act); y10 = dcvic_act(y10, act); y11 = dcvic_act(y11, act);
-                const long long co_off = (long long)co * HW;
-                if (in_y0) {
-                    if (rb) { const float2 rv = *reinterpret_cast<const float2*>(rb + co_off); y00 += rv.x; y01 += rv.y; }
-                    *reinterpret_cast<float2*>(ob + co_off) = make_float2(y00, y01);
-                }
-                if (in_y1) {
-                    if (rb) { const float2 rv = *reinterpret_cast<const float2*>(rb + co_off + K.W); y10 += rv.x; y11 += rv.y; }
-                    *reinterpret_cast<float2*>(ob + co_off + K.W) = make_float2(y10, y11);
-                }
-            }
-        }
-    });
 }
 
 extern "C" size_t dcvic_wino_packed_bytes(int Cin, int Cout) {
@@ -390,7 +439,11 @@ extern "C" int dcvic_conv3x3_wino_f32(int Cin, int Cout, const float* packed, co
     static std::atomic<unsigned> attr_mask{0};
     if (dcvic_first_use_on_device(attr_mask))
         hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_wino_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    conv3x3_wino_kernel<<<K.nblocks, WN_THREADS, WN_LDS_FLOATS * sizeof(float), (hipStream_t)stream>>>(K);
+    // persistent grid: one workgroup per CU (152 KiB of LDS each), a multiple of the 8 XCDs; each walks its share of the tiles
+    int grid = (dcvic_num_cu() / NXCD) * NXCD;
+    if (grid < NXCD) grid = NXCD;
+    if ((long long)grid > blocks) grid = (int)((blocks + NXCD - 1) / NXCD) * NXCD;
+    conv3x3_wino_kernel<<<grid, WN_THREADS, WN_LDS_FLOATS * sizeof(float), (hipStream_t)stream>>>(K);
     DCVIC_CHECK_LAUNCH("conv3x3_wino");
     return DCVIC_OK;
 }

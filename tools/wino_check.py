@@ -50,6 +50,9 @@ def run(Cin, Cout, H, W, N, reps=5, res=False, act=0, check=True, srcs_split=Non
 
 if __name__ == "__main__":
     mode = sys.argv[1] if len(sys.argv) > 1 else "all"
+    if mode == "one":       # one Cin Cout H W N [res] [reps]: a single shape, Winograd only (for rocprofv3 --pmc)
+        a = [int(v) for v in sys.argv[2:]]
+        run(a[0], a[1], a[2], a[3], a[4], reps=a[6] if len(a) > 6 else 5, res=bool(a[5]) if len(a) > 5 else False, check=False)
     if mode in ("all", "check"):
         run(8, 64, 8, 32, 1)
         run(16, 64, 10, 30, 2)
