@@ -75,6 +75,8 @@ __global__ void wino_pack_kernel(const float* __restrict__ w, float* __restrict_
     wp[i] = v;
 }
 
+// DBG (timing experiments, wrong results, DCVIC_WINO_DEBUG=16*DBG): 1 no stage barrier, 2 no transform, 4 no DMA, 8 no operand waits
+template <int DBG>
 __global__ __launch_bounds__(WN_THREADS, 2) void conv3x3_wino_kernel(const ConvKArgs K) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x;
@@ -83,6 +85,7 @@ __global__ __launch_bounds__(WN_THREADS, 2) void conv3x3_wino_kernel(const ConvK
 
     const long long HW = (long long)K.H * K.W;
     const int S = K.n_chunks;                                     // stages (8-channel chunks) per tile
+    const long long x_stride = (long long)KC * HW;                // floats between two stages of one source
 
     // ---- PERSISTENT workgroup: XCD x = blockIdx.x % 8 owns the contiguous range [xs, xe) of tile indices (cotile fastest, so
     // the workgroups of one L2 share input patches and weight slabs); slot j = blockIdx.x / 8 takes tiles xs + j, xs + j + J, ...
@@ -109,7 +112,6 @@ __global__ __launch_bounds__(WN_THREADS, 2) void conv3x3_wino_kernel(const ConvK
 
     // ---- raw-patch DMA: element e = tid + s*512 of [8 ch][10][34]; running pointers, advanced per stage, re-derived per tile
     const float* xp[WN_XSLOTS];
-    unsigned xst[WN_XSLOTS];
     int poff[WN_XSLOTS];
     int x_left = 0, x_n = 0, x_b = first, x_next = 0;             // X stream: image, tile index, chunk inside the tile
     auto x_rebase = [&](int c) __attribute__((always_inline)) {                                  // pointers for absolute input channel c of image x_n
@@ -117,7 +119,7 @@ __global__ __launch_bounds__(WN_THREADS, 2) void conv3x3_wino_kernel(const ConvK
         if (c >= K.srcC[0]) { c -= K.srcC[0]; si = 1; if (c >= K.srcC[1]) { c -= K.srcC[1]; si = 2; } }
         const float* base = K.src[si] + (long long)x_n * K.src_bs[si] + (long long)c * HW;
 #pragma unroll
-        for (int s = 0; s < WN_XSLOTS; ++s) xp[s] = poff[s] >= 0 ? base + poff[s] : dcvic_wino_zero;
+        for (int s = 0; s < WN_XSLOTS; ++s) xp[s] = (poff[s] >= 0 && !(K.TG & 1)) ? base + poff[s] : dcvic_wino_zero;
         x_left = K.srcC[si] - c;
     };
     auto x_setup = [&](int b) __attribute__((always_inline)) {
@@ -135,18 +137,16 @@ __global__ __launch_bounds__(WN_THREADS, 2) void conv3x3_wino_kernel(const ConvK
                 if (iy >= 0 && iy < K.H && ix >= 0 && ix < K.W) o = (int)(k * HW) + iy * K.W + ix;
             }
             poff[s] = o;
-            xst[s] = o >= 0 ? (unsigned)(KC * HW * 4) : 0u;
         }
         x_rebase(0);
     };
     x_setup(first);
     // ---- weight DMA: the stage's 32 KiB slab is already the LDS image; thread moves float4 #(tid + j*512)
-    const float* wp4[4];
+    const float* wp0;                                             // this thread's first float4 of the stage's slab
     int u_b = first, u_next = 0;                                  // U stream
     auto u_setup = [&](int b) __attribute__((always_inline)) {
         const float* wbase = K.wp + (long long)(b % K.n_cotiles) * S * (long long)WN_US;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) wp4[j] = wbase + 4 * (tid + j * WN_THREADS);
+        wp0 = wbase + 4 * tid;
     };
     u_setup(first);
     // ---- input transform: this thread's (channel, tile) of a stage
@@ -200,14 +200,16 @@ __global__ __launch_bounds__(WN_THREADS, 2) void conv3x3_wino_kernel(const ConvK
         const float val = tv[p];                                  // (asm operands inside a generic lambda do not capture)
         asm volatile("ds_write_b32 %0, %1 offset:%2" :: "v"(vaddr), "v"(val), "n"(4 * 512 * p) : "memory");
     };
-    f32x2 opA[2];                                                 // operand sets, ping-pong by position parity
-    f32x4 opB[2];
-    auto op_load = [&](auto p_, unsigned ua, unsigned va) {
-        constexpr int p = decltype(p_)::value;
-        f32x2& ra = opA[p & 1];
-        f32x4& rb = opB[p & 1];
-        asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(ra) : "v"(ua), "n"(4 * 512 * p));
-        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(rb) : "v"(va), "n"(4 * 512 * p));
+    f32x2 opA[2][2];                                              // [set = pair parity][position inside the pair]
+    f32x4 opB[2][2];
+    auto op_load = [&](auto j_, unsigned ua, unsigned va) {       // operands of positions 2j and 2j + 1
+        constexpr int j = decltype(j_)::value;
+        f32x2 &a0 = opA[j & 1][0], &a1 = opA[j & 1][1];
+        f32x4 &b0 = opB[j & 1][0], &b1 = opB[j & 1][1];
+        asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(a0) : "v"(ua), "n"(4 * 512 * (2 * j)));
+        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(b0) : "v"(va), "n"(4 * 512 * (2 * j)));
+        asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(a1) : "v"(ua), "n"(4 * 512 * (2 * j + 1)));
+        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(b1) : "v"(va), "n"(4 * 512 * (2 * j + 1)));
     };
     auto dma_x = [&](auto s_, int buf) {
         constexpr int sl = decltype(s_)::value;
@@ -215,7 +217,7 @@ __global__ __launch_bounds__(WN_THREADS, 2) void conv3x3_wino_kernel(const ConvK
     };
     auto dma_u = [&](auto j_, int buf) {
         constexpr int j = decltype(j_)::value;
-        __builtin_amdgcn_global_load_lds(reinterpret_cast<const float4*>(wp4[j]), (lds_ptr_t)(smem + WN_OFF_U + buf * WN_US + (wave * 64 + j * WN_THREADS) * 4), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds(reinterpret_cast<const float4*>(wp0 + j * (4 * WN_THREADS)), (lds_ptr_t)(smem + WN_OFF_U + buf * WN_US + (wave * 64 + j * WN_THREADS) * 4), 16, 0, 0);
     };
     auto x_advance = [&]() __attribute__((always_inline)) {                                     // after the DMA of an X stage: on to the next stage of the stream
         if (++x_next == S) {
@@ -226,7 +228,7 @@ __global__ __launch_bounds__(WN_THREADS, 2) void conv3x3_wino_kernel(const ConvK
             x_left -= KC;
             if (x_left > 0) {
 #pragma unroll
-                for (int sl = 0; sl < WN_XSLOTS; ++sl) xp[sl] = reinterpret_cast<const float*>(reinterpret_cast<const char*>(xp[sl]) + xst[sl]);
+                for (int sl = 0; sl < WN_XSLOTS; ++sl) xp[sl] += (poff[sl] >= 0 && !(K.TG & 1)) ? x_stride : 0ll;   // (padding lanes stay on the zero word)
             } else {
                 x_rebase(x_next * KC);
             }
@@ -238,8 +240,7 @@ __global__ __launch_bounds__(WN_THREADS, 2) void conv3x3_wino_kernel(const ConvK
             u_b += J;
             if (u_b < xe) u_setup(u_b);
         } else {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) wp4[j] += WN_US;
+            if (!(K.TG & 2)) wp0 += WN_US;
         }
     };
 
@@ -335,26 +336,28 @@ __global__ __launch_bounds__(WN_THREADS, 2) void conv3x3_wino_kernel(const ConvK
         const unsigned ua = op_u + (unsigned)(cur * WN_US * 4), va = op_v + (unsigned)(cur * WN_VS * 4);
         const unsigned xaddr = t_src + (unsigned)(nxt * WN_XS * 4), vaddr = t_dst + (unsigned)(nxt * WN_VS * 4);
         op_load(std::integral_constant<int, 0>{}, ua, va);
-        // 64 MFMA slots = 16 positions x (k-step, block).  In front of a position's four MFMAs: wait for its operands, then
-        // request the next position's; behind its MFMAs one piece of the stage's other work issues in their shadow: the
-        // DMA of U(g+1) and X(g+2), the transform of X(g+1) into V(g+1).
-        dcvic_static_for<0, 16>([&](auto p_) {
-            constexpr int pp = decltype(p_)::value;
-            WN_WAIT_LDS();
-            if constexpr (pp < 15) op_load(std::integral_constant<int, pp + 1>{}, ua, va);
+        // 64 MFMA slots = 8 position pairs x (position, k-step, block).  In front of a pair's eight MFMAs: wait for its operands,
+        // then request the next pair's (they have eight MFMAs to arrive); behind each MFMA a piece of the stage's other work
+        // issues in its shadow: the DMA of U(g+1) and X(g+2), the transform of X(g+1) into V(g+1).
+        dcvic_static_for<0, 8>([&](auto j_) {
+            constexpr int j = decltype(j_)::value;
+            if constexpr (!(DBG & 8)) WN_WAIT_LDS();
+            if constexpr (j < 7) op_load(std::integral_constant<int, j + 1>{}, ua, va);
             WN_FENCE();
-            dcvic_static_for<0, 4>([&](auto i_) {
-                constexpr int i = decltype(i_)::value, ks = i >> 1, blk = i & 1;
-                acc[pp][blk] = __builtin_amdgcn_mfma_f32_16x16x4f32(opA[pp & 1][ks], opB[pp & 1][blk * 2 + ks], acc[pp][blk], 0, 0, 0);
+            dcvic_static_for<0, 8>([&](auto i_) {
+                constexpr int i = decltype(i_)::value, pq = i >> 2, ks = (i >> 1) & 1, blk = i & 1, pp = 2 * j + pq;
+                acc[pp][blk] = __builtin_amdgcn_mfma_f32_16x16x4f32(opA[j & 1][pq][ks], opB[j & 1][pq][blk * 2 + ks], acc[pp][blk], 0, 0, 0);
                 WN_FENCE();
-                if constexpr (more1 && pp < 2 && (i & 1) == 0) dma_u(std::integral_constant<int, 2 * pp + (i >> 1)>{}, nxt);
-                if constexpr (more2 && pp >= 2 && pp < 5 && (i & 1) == 0) dma_x(std::integral_constant<int, 2 * (pp - 2) + (i >> 1)>{}, cur);
-                if constexpr (more1 && pp >= 6 && pp < 8 && (i & 1) == 0) t_load(std::integral_constant<int, 2 * (pp - 6) + (i >> 1)>{}, xaddr);
-                if constexpr (more1 && pp == 9) t_compute(std::integral_constant<int, i>{});
-                if constexpr (more1 && pp == 10) t_rows(std::integral_constant<int, i>{});
-                if constexpr (more1 && pp >= 11 && pp < 15) {
-                    t_store(std::integral_constant<int, 4 * (pp - 11) + i>{}, vaddr);
-                }
+                // slot sl = 8j + i.  DMA pieces one every 4th slot (all eight waves run this schedule in step: ten pieces in ten
+                // consecutive slots put 80 VMEM instructions into the CU's address unit at once and stalled the issuing waves --
+                // measured 16 % of the kernel), U first (needed right after the barrier), then X; transform work after them.
+                constexpr int sl = 8 * j + i;
+                if constexpr (!(DBG & 4) && more1 && (sl & 3) == 1 && sl < 16) dma_u(std::integral_constant<int, sl / 4>{}, nxt);
+                if constexpr (!(DBG & 4) && more2 && (sl & 3) == 1 && sl >= 16 && sl < 40) dma_x(std::integral_constant<int, sl / 4 - 4>{}, cur);
+                if constexpr (!(DBG & 2) && more1 && j == 2 && (i & 3) >= 2) t_load(std::integral_constant<int, (i >> 2) * 2 + (i & 1)>{}, xaddr);
+                if constexpr (!(DBG & 2) && more1 && j == 3 && (i & 3) >= 2) t_compute(std::integral_constant<int, (i >> 2) * 2 + (i & 1)>{});
+                if constexpr (!(DBG & 2) && more1 && j == 4 && (i & 3) >= 2) t_rows(std::integral_constant<int, (i >> 2) * 2 + (i & 1)>{});
+                if constexpr (!(DBG & 2) && more1 && (j == 5 || j == 6)) t_store(std::integral_constant<int, 8 * (j - 5) + i>{}, vaddr);
                 WN_FENCE();
             });
         });
@@ -369,7 +372,7 @@ __global__ __launch_bounds__(WN_THREADS, 2) void conv3x3_wino_kernel(const ConvK
             }
         }
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-        __syncthreads();
+        if constexpr (!(DBG & 1)) __syncthreads();
         WN_FENCE();
     };
     {
@@ -429,6 +432,7 @@ extern "C" int dcvic_conv3x3_wino_f32(int Cin, int Cout, const float* packed, co
     K.out = io->out; K.out_bs = io->out_batch_stride; K.bias = io->bias; K.act = io->act;
     K.res = io->res; K.res_bs = io->res_batch_stride;
     K.wp = packed;
+    { const char* e = getenv("DCVIC_WINO_DEBUG"); K.TG = e ? atoi(e) : 0; }   // timing experiments only (wrong results)
     K.n_chunks = (Cin + KC - 1) / KC;
     K.n_cotiles = (Cout + WN_CO - 1) / WN_CO;
     K.tiles_y = (io->H + WN_TH - 1) / WN_TH;
@@ -437,13 +441,17 @@ extern "C" int dcvic_conv3x3_wino_f32(int Cin, int Cout, const float* packed, co
     DCVIC_CHECK_ARG(blocks < (1ll << 31), "conv3x3_wino: grid too large");
     K.nblocks = (int)blocks;
     static std::atomic<unsigned> attr_mask{0};
-    if (dcvic_first_use_on_device(attr_mask))
-        hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_wino_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    const int dbg = K.TG >> 4;
+    K.TG &= 15;
+    auto kern = dbg == 1 ? conv3x3_wino_kernel<1> : dbg == 2 ? conv3x3_wino_kernel<2> : dbg == 4 ? conv3x3_wino_kernel<4> : dbg == 8 ? conv3x3_wino_kernel<8> :
+                dbg == 6 ? conv3x3_wino_kernel<6> : conv3x3_wino_kernel<0>;
+    if (dcvic_first_use_on_device(attr_mask) || dbg)
+        hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     // persistent grid: one workgroup per CU (152 KiB of LDS each), a multiple of the 8 XCDs; each walks its share of the tiles
     int grid = (dcvic_num_cu() / NXCD) * NXCD;
     if (grid < NXCD) grid = NXCD;
     if ((long long)grid > blocks) grid = (int)((blocks + NXCD - 1) / NXCD) * NXCD;
-    conv3x3_wino_kernel<<<grid, WN_THREADS, WN_LDS_FLOATS * sizeof(float), (hipStream_t)stream>>>(K);
+    kern<<<grid, WN_THREADS, WN_LDS_FLOATS * sizeof(float), (hipStream_t)stream>>>(K);
     DCVIC_CHECK_LAUNCH("conv3x3_wino");
     return DCVIC_OK;
 }
