@@ -9,8 +9,8 @@
 // direct sum at the 1e-6 relative level (tolerances in tests/test_gpu_kernels.py::test_wino_*).
 //
 // One workgroup = 512 threads = 8 waves (2 per SIMD) on 64 output channels x (8 rows x 32 columns) = 64 tiles of 2x2.
-//   * a pipeline stage is 8 input channels.  Per stage the raw input patch (8 ch x 10 x 34, zero padded through a zero
-//     word) and the pre-transformed weights U (16 positions x 8 ch x 64 co = 32 KiB, packed by wino_pack_kernel in the
+//   * a pipeline stage is 8 input channels.  Per stage the raw input patch (8 ch x 10 rows x ten 16-byte segments, zero
+//     padded through a zero source) and the pre-transformed weights U (16 positions x 8 ch x 64 co = 32 KiB, packed by wino_pack_kernel in the
 //     exact LDS image) arrive by LDS-DMA (`global_load_lds_dword / _dwordx4`), two stages / one stage ahead;
 //   * every thread transforms ONE (channel, tile) 4x4 patch per stage (8 ds_read_b64, 32 adds, 16 ds_write_b32) into the
 //     V image of the NEXT stage while the MFMAs of the current stage run;
@@ -33,12 +33,13 @@ __device__ float dcvic_wino_zero[16];   // zero-initialised: source of padded la
 
 #define WN_TH 8
 #define WN_TW 32
-#define WN_PW 34
-#define WN_PLANE 340
+#define WN_PW 40          // LDS row: columns ox0 - 4 .. ox0 + 35 as ten 16-byte segments; the patch's 34 columns sit at 3 .. 36
+#define WN_PLANE 400
+#define WN_SEGS 800        // float4 segments of a stage: 8 ch x 10 rows x 10
 #define WN_CO 64
 #define WN_THREADS 512
-#define WN_XSLOTS 6
-#define WN_XS 3072
+#define WN_XSLOTS 2
+#define WN_XS 3328         // floats: slot 1 is issued by waves 0..4 only, its idle lanes write zeros behind the patch
 #define WN_US 8192
 #define WN_VS 8192
 #define WN_OFF_U (2 * WN_XS)
@@ -75,7 +76,8 @@ __global__ void wino_pack_kernel(const float* __restrict__ w, float* __restrict_
     wp[i] = v;
 }
 
-// DBG (timing experiments, wrong results, DCVIC_WINO_DEBUG=16*DBG): 1 no stage barrier, 2 no transform, 4 no DMA, 8 no operand waits
+// DBG (timing experiments, wrong results, DCVIC_WINO_DEBUG=16*DBG): 1 no stage barrier, 2 no transform, 4 no DMA, 8 no operand waits,
+// 16 no X DMA, 32 no U DMA, 64 no vmcnt wait in front of the stage barrier
 template <int DBG>
 __global__ __launch_bounds__(WN_THREADS, 2) void conv3x3_wino_kernel(const ConvKArgs K) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -128,12 +130,12 @@ __global__ __launch_bounds__(WN_THREADS, 2) void conv3x3_wino_kernel(const ConvK
         const int iy0 = oy0 - 1, ix0 = ox0 - 1;
 #pragma unroll
         for (int s = 0; s < WN_XSLOTS; ++s) {
-            const int e = tid + s * WN_THREADS;
+            const int e = tid + s * WN_THREADS;                    // float4 segment e of [8 ch][10 rows][10 segments]
             int o = -1;
-            if (e < KC * WN_PLANE) {
-                const int k = e / WN_PLANE, r = e - k * WN_PLANE;
-                const int py = r / WN_PW, px = r - py * WN_PW;
-                const int iy = iy0 + py, ix = ix0 + px;
+            if (e < WN_SEGS) {
+                const int k = e / 100, r = e - k * 100;
+                const int py = r / 10, seg = r - py * 10;
+                const int iy = iy0 + py, ix = ix0 - 3 + 4 * seg;   // W % 4 == 0: a segment is entirely inside or outside the row
                 if (iy >= 0 && iy < K.H && ix >= 0 && ix < K.W) o = (int)(k * HW) + iy * K.W + ix;
             }
             poff[s] = o;
@@ -153,7 +155,7 @@ __global__ __launch_bounds__(WN_THREADS, 2) void conv3x3_wino_kernel(const ConvK
     //   wave -> (th, k); lane -> (n, blk, ks);  channel 4ks + k, tile row 2th + blk, tile column n
     const int t_th = wave >> 2, t_k = wave & 3;
     const int t_n = lane & 15, t_blk = (lane >> 4) & 1, t_ks = lane >> 5;
-    const unsigned t_src = 4u * (unsigned)((4 * t_ks + t_k) * WN_PLANE + (2 * (2 * t_th + t_blk)) * WN_PW + 2 * t_n);
+    const unsigned t_src = 4u * (unsigned)((4 * t_ks + t_k) * WN_PLANE + (2 * (2 * t_th + t_blk)) * WN_PW + 2 * t_n + 3);
     const unsigned t_dst = 4u * (unsigned)(WN_OFF_V + ((t_th * 4 + t_k) * 16 + t_n) * 4 + t_blk * 2 + t_ks);
     // ---- MFMA operands: wave -> (cg = co group, th = tile half)
     const int cg = wave & 3, th = wave >> 2;
@@ -177,9 +179,9 @@ __global__ __launch_bounds__(WN_THREADS, 2) void conv3x3_wino_kernel(const ConvK
     float td[4][4];                                               // raw 4x4 patch of the transform
     auto t_load = [&](auto r_, unsigned xaddr) {                  // row r of the patch: two ds_read_b64
         constexpr int r = decltype(r_)::value;
-        f32x2 lo, hi;
-        asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(lo) : "v"(xaddr), "n"(4 * r * WN_PW));
-        asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(hi) : "v"(xaddr), "n"(4 * r * WN_PW + 8));
+        f32x2 lo, hi;                                             // (odd dword offset: two dwords per read instead of one ds_read_b64)
+        asm volatile("ds_read2_b32 %0, %1 offset0:%2 offset1:%3" : "=v"(lo) : "v"(xaddr), "n"(r * WN_PW), "n"(r * WN_PW + 1));
+        asm volatile("ds_read2_b32 %0, %1 offset0:%2 offset1:%3" : "=v"(hi) : "v"(xaddr), "n"(r * WN_PW + 2), "n"(r * WN_PW + 3));
         td[r][0] = lo[0]; td[r][1] = lo[1]; td[r][2] = hi[0]; td[r][3] = hi[1];
     };
     float tv[16];
@@ -213,7 +215,8 @@ __global__ __launch_bounds__(WN_THREADS, 2) void conv3x3_wino_kernel(const ConvK
     };
     auto dma_x = [&](auto s_, int buf) {
         constexpr int sl = decltype(s_)::value;
-        __builtin_amdgcn_global_load_lds(xp[sl], (lds_ptr_t)(smem + buf * WN_XS + wave * 64 + sl * WN_THREADS), 4, 0, 0);
+        if (sl == 0 || wave < 5)                                  // (wave-uniform: segments 512 .. 799 live in waves 0 .. 4 of slot 1)
+            __builtin_amdgcn_global_load_lds(reinterpret_cast<const float4*>(xp[sl]), (lds_ptr_t)(smem + buf * WN_XS + (wave * 64 + sl * WN_THREADS) * 4), 16, 0, 0);
     };
     auto dma_u = [&](auto j_, int buf) {
         constexpr int j = decltype(j_)::value;
@@ -329,20 +332,32 @@ __global__ __launch_bounds__(WN_THREADS, 2) void conv3x3_wino_kernel(const ConvK
     WN_WAIT_LDS();
     __syncthreads();
     WN_FENCE();
+    op_load(std::integral_constant<int, 0>{}, op_u, op_v);        // first operands of stage 0
     // more1 / more2: a stage g + 1 / g + 2 exists in the stream (compile-time: no branches between the MFMAs)
     auto run_stage = [&](auto more1_, auto more2_, int g) __attribute__((always_inline)) {
         constexpr bool more1 = decltype(more1_)::value, more2 = decltype(more2_)::value;
         const int cur = g & 1, nxt = cur ^ 1;
         const unsigned ua = op_u + (unsigned)(cur * WN_US * 4), va = op_v + (unsigned)(cur * WN_VS * 4);
         const unsigned xaddr = t_src + (unsigned)(nxt * WN_XS * 4), vaddr = t_dst + (unsigned)(nxt * WN_VS * 4);
-        op_load(std::integral_constant<int, 0>{}, ua, va);
         // 64 MFMA slots = 8 position pairs x (position, k-step, block).  In front of a pair's eight MFMAs: wait for its operands,
         // then request the next pair's (they have eight MFMAs to arrive); behind each MFMA a piece of the stage's other work
         // issues in its shadow: the DMA of U(g+1) and X(g+2), the transform of X(g+1) into V(g+1).
+        // The stage BARRIER sits in front of the LAST pair: by then every operand read of this stage has returned, the
+        // transform's stores and this wave's DMA pieces have landed; behind it the first operands of stage g + 1 are requested
+        // and arrive under the last pair's MFMAs -- no LDS round trip between two stages' MFMAs (pair 0 of the very first stage
+        // is requested by the prologue).
         dcvic_static_for<0, 8>([&](auto j_) {
             constexpr int j = decltype(j_)::value;
-            if constexpr (!(DBG & 8)) WN_WAIT_LDS();
-            if constexpr (j < 7) op_load(std::integral_constant<int, j + 1>{}, ua, va);
+            if constexpr (j < 7) {
+                if constexpr (!(DBG & 8)) WN_WAIT_LDS();
+                op_load(std::integral_constant<int, j + 1>{}, ua, va);
+            } else {
+                if constexpr (DBG & 64) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+                if constexpr (!(DBG & 1)) __syncthreads();
+                WN_FENCE();
+                if constexpr (more1) op_load(std::integral_constant<int, 0>{}, op_u + (unsigned)(nxt * WN_US * 4), op_v + (unsigned)(nxt * WN_VS * 4));
+            }
             WN_FENCE();
             dcvic_static_for<0, 8>([&](auto i_) {
                 constexpr int i = decltype(i_)::value, pq = i >> 2, ks = (i >> 1) & 1, blk = i & 1, pp = 2 * j + pq;
@@ -352,8 +367,8 @@ __global__ __launch_bounds__(WN_THREADS, 2) void conv3x3_wino_kernel(const ConvK
                 // consecutive slots put 80 VMEM instructions into the CU's address unit at once and stalled the issuing waves --
                 // measured 16 % of the kernel), U first (needed right after the barrier), then X; transform work after them.
                 constexpr int sl = 8 * j + i;
-                if constexpr (!(DBG & 4) && more1 && (sl & 3) == 1 && sl < 16) dma_u(std::integral_constant<int, sl / 4>{}, nxt);
-                if constexpr (!(DBG & 4) && more2 && (sl & 3) == 1 && sl >= 16 && sl < 40) dma_x(std::integral_constant<int, sl / 4 - 4>{}, cur);
+                if constexpr (!(DBG & 36) && more1 && (sl & 3) == 1 && sl < 16) dma_u(std::integral_constant<int, sl / 4>{}, nxt);
+                if constexpr (!(DBG & 20) && more2 && (sl & 3) == 1 && sl >= 16 && sl < 24) dma_x(std::integral_constant<int, sl / 4 - 4>{}, cur);
                 if constexpr (!(DBG & 2) && more1 && j == 2 && (i & 3) >= 2) t_load(std::integral_constant<int, (i >> 2) * 2 + (i & 1)>{}, xaddr);
                 if constexpr (!(DBG & 2) && more1 && j == 3 && (i & 3) >= 2) t_compute(std::integral_constant<int, (i >> 2) * 2 + (i & 1)>{});
                 if constexpr (!(DBG & 2) && more1 && j == 4 && (i & 3) >= 2) t_rows(std::integral_constant<int, (i >> 2) * 2 + (i & 1)>{});
@@ -371,8 +386,6 @@ __global__ __launch_bounds__(WN_THREADS, 2) void conv3x3_wino_kernel(const ConvK
                 stage_bias(c_b, c_par);
             }
         }
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-        if constexpr (!(DBG & 1)) __syncthreads();
         WN_FENCE();
     };
     {
@@ -406,14 +419,15 @@ extern "C" int dcvic_conv3x3_wino_f32(int Cin, int Cout, const float* packed, co
     for (int i = 0; i < io->n_src; ++i) {
         DCVIC_CHECK_ARG(io->src[i].ptr && io->src[i].C > 0 && io->src[i].C % KC == 0, "conv3x3_wino: source %d needs a multiple of 8 channels", i);
         DCVIC_CHECK_ARG(io->src[i].batch_stride >= (long long)io->src[i].C * io->H * io->W, "conv3x3_wino: source %d batch stride too small", i);
-        DCVIC_CHECK_ARG((reinterpret_cast<uintptr_t>(io->src[i].ptr) & 3) == 0, "conv3x3_wino: source %d misaligned", i);
+        DCVIC_CHECK_ARG((reinterpret_cast<uintptr_t>(io->src[i].ptr) & 15) == 0 && (io->src[i].batch_stride & 3) == 0,
+                        "conv3x3_wino: source %d must be 16-byte aligned (16-byte LDS-DMA segments)", i);
         csum += io->src[i].C;
     }
     DCVIC_CHECK_ARG(csum == Cin, "conv3x3_wino: sources carry %d channels, layer expects %d", csum, Cin);
     DCVIC_CHECK_ARG(io->N > 0 && io->H > 0 && io->W > 0, "conv3x3_wino: bad sizes");
     DCVIC_CHECK_ARG(io->Hout == io->H && io->Wout == io->W && io->Hfull == io->H && io->Wfull == io->W && io->osy == 1 && io->osx == 1 &&
                     io->ooy == 0 && io->oox == 0, "conv3x3_wino: stride-1 pad-1 geometry only");
-    DCVIC_CHECK_ARG((io->W & 1) == 0, "conv3x3_wino: width must be even");
+    DCVIC_CHECK_ARG((io->W & 3) == 0, "conv3x3_wino: width must be a multiple of 4");
     DCVIC_CHECK_ARG(!io->aff_scale && !io->aff_shift && !io->init, "conv3x3_wino: affine / init epilogues are not supported");
     DCVIC_CHECK_ARG((long long)io->H * io->W * KC < (1ll << 31), "conv3x3_wino: plane too large");
     DCVIC_CHECK_ARG(io->out_batch_stride >= (long long)Cout * io->H * io->W && (io->out_batch_stride & 1) == 0 &&
@@ -444,7 +458,7 @@ extern "C" int dcvic_conv3x3_wino_f32(int Cin, int Cout, const float* packed, co
     const int dbg = K.TG >> 4;
     K.TG &= 15;
     auto kern = dbg == 1 ? conv3x3_wino_kernel<1> : dbg == 2 ? conv3x3_wino_kernel<2> : dbg == 4 ? conv3x3_wino_kernel<4> : dbg == 8 ? conv3x3_wino_kernel<8> :
-                dbg == 6 ? conv3x3_wino_kernel<6> : conv3x3_wino_kernel<0>;
+                dbg == 6 ? conv3x3_wino_kernel<6> : dbg == 16 ? conv3x3_wino_kernel<16> : dbg == 32 ? conv3x3_wino_kernel<32> : dbg == 64 ? conv3x3_wino_kernel<64> : conv3x3_wino_kernel<0>;
     if (dcvic_first_use_on_device(attr_mask) || dbg)
         hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     // persistent grid: one workgroup per CU (152 KiB of LDS each), a multiple of the 8 XCDs; each walks its share of the tiles

@@ -664,3 +664,82 @@ def test_conv3x3_dma_96_channel_tiles_bit_identical(dev):
             assert torch.equal(outs["dma"][0], outs["generic"][0]) and torch.equal(outs["dma"][1], outs["generic"][1]), f"case {ci}"
     finally:
         L.dcvic_conv_set_tuning(1, 1, 2)
+
+
+# ------------------------------------------------------------------------------------------- Winograd F(2x2, 3x3)
+WINO_CASES = [
+    # Cin, Cout, H, W, N, n_src split, residual, act
+    (8, 64, 8, 32, 1, None, False, 0),            # exactly one workgroup tile, one stage
+    (16, 64, 10, 28, 2, None, False, 0),          # ragged tile, rows / columns masked
+    (64, 128, 33, 72, 2, None, True, 3),          # odd height, residual + swish, three column tiles
+    (128, 192, 64, 64, 2, None, True, 0),         # three 64-channel tiles
+    (256, 96, 40, 48, 1, [192, 64], False, 2),    # two sources (virtual concat), Cout not a multiple of 64
+    (704, 512, 32, 32, 2, [192, 512], False, 0),  # the 1/8-level fusion block: cat[cond 192, dec 512] -> 512
+    (128, 128, 256, 256, 2, None, True, 0),       # the 256^2 decoder layer: more tiles than workgroups (persistent loop)
+]
+
+
+@pytest.mark.parametrize("case", WINO_CASES)
+def test_wino_conv3x3(dev, case):
+    """dcvic_conv3x3_wino_f32 vs torch conv2d evaluated in fp64.  Winograd re-associates the sum, so the comparison is a
+    tolerance: 2e-6 of the output's max -- 4x the largest error measured on MI355X over these cases (4.8e-7), and never
+    worse than the direct kernel's own error against the same fp64 reference (checked alongside)."""
+    from dc_vic_amd import ops
+    Cin, Cout, H, W, N, split, res, act = case
+    x = rnd(N, Cin, H, W, seed=11)
+    w = rnd(Cout, Cin, 3, 3, seed=12, scale=(Cin * 9) ** -0.5)
+    b = rnd(Cout, seed=13, scale=0.1)
+    r = rnd(N, Cout, H, W, seed=14) if res else None
+    ref = F.conv2d(x.double(), w.double(), b.double(), padding=1)
+    if act == 3:
+        ref = ref * torch.sigmoid(ref)
+    elif act == 2:
+        ref = torch.where(ref > 0, ref, 0.2 * ref)
+    if res:
+        ref = ref + r.double()
+    direct = ops.ConvPlan(w.to(dev), b.to(dev), "conv", pad=(1, 1))
+    wino = ops.ConvPlan(w.to(dev), b.to(dev), "conv", pad=(1, 1))
+    wino.wino = "force"
+    xs = x.to(dev)
+    srcs = xs if split is None else [t.contiguous() for t in torch.split(xs, split, dim=1)]
+    rd = r.to(dev) if res else None
+    yd = direct(srcs, act=act, res=rd)
+    yw = wino(srcs, act=act, res=rd)
+    sc = float(ref.abs().max())
+    ed = float((yd.double().cpu() - ref).abs().max()) / sc
+    ew = float((yw.double().cpu() - ref).abs().max()) / sc
+    assert ew < 2e-6, (ew, ed)
+    assert ew < 4 * ed + 1e-7, (ew, ed)
+
+
+def test_wino_batch_invariant_and_deterministic(dev):
+    """The tile grid and the per-position reduction order never depend on N: an image convolved alone or inside a batch
+    gives the same bits, and so do two runs."""
+    from dc_vic_amd import ops
+    x = rnd(5, 128, 64, 96, seed=21).to(dev)
+    w = rnd(256, 128, 3, 3, seed=22, scale=(128 * 9) ** -0.5).to(dev)
+    b = rnd(256, seed=23).to(dev)
+    plan = ops.ConvPlan(w, b, "conv", pad=(1, 1))
+    plan.wino = "force"
+    y5 = plan(x)
+    y5b = plan(x)
+    y1 = plan(x[3:4].contiguous())
+    assert torch.equal(y5, y5b)
+    assert torch.equal(y5[3:4], y1)
+
+
+def test_wino_eligibility_is_a_function_of_layer_and_image_only(dev):
+    """ConvPlan._wino_ok must not look at N (a reconstruction may not depend on its batch), must refuse odd widths,
+    unaligned sources, and maps that waste the 8 x 32 tiles; such layers run on the direct kernels."""
+    from dc_vic_amd import ops
+    w = rnd(128, 128, 3, 3, seed=31, scale=0.03).to(dev)
+    plan = ops.ConvPlan(w, None, "conv", pad=(1, 1))
+    plan.wino = True
+    mk = lambda n, c, h, ww: [torch.empty((n, c, h, ww), device=dev)]
+    assert plan._wino_ok(mk(1, 128, 256, 256), 1, 256, 256) and plan._wino_ok(mk(32, 128, 256, 256), 32, 256, 256)
+    assert plan._wino_ok(mk(1, 128, 32, 32), 1, 32, 32) == plan._wino_ok(mk(32, 128, 32, 32), 32, 32, 32)
+    assert not plan._wino_ok(mk(1, 128, 64, 62), 1, 64, 62)          # width not a multiple of 4
+    assert not plan._wino_ok(mk(1, 128, 8, 8), 1, 8, 8)              # 8 x 8 map in an 8 x 32 tile
+    assert not plan._wino_ok([torch.empty((1, 124, 64, 64), device=dev), torch.empty((1, 4, 64, 64), device=dev)], 1, 64, 64)
+    y_auto = plan(torch.zeros((1, 128, 8, 8), device=dev))            # falls back to the direct kernel
+    assert y_auto.shape == (1, 128, 8, 8)

@@ -55,8 +55,8 @@ if __name__ == "__main__":
         run(a[0], a[1], a[2], a[3], a[4], reps=a[6] if len(a) > 6 else 5, res=bool(a[5]) if len(a) > 5 else False, check=False)
     if mode in ("all", "check"):
         run(8, 64, 8, 32, 1)
-        run(16, 64, 10, 30, 2)
-        run(64, 128, 33, 70, 2, res=True, act=3)
+        run(16, 64, 10, 28, 2)
+        run(64, 128, 33, 72, 2, res=True, act=3)
         run(128, 192, 64, 64, 2, res=True)
         run(256, 128, 40, 48, 1, srcs_split=[192, 64])
     if mode in ("all", "bench"):
