@@ -151,6 +151,8 @@ class Encoder(nn.Module):
         self.mid.block_2 = ResnetBlock(block_in, block_in)
         self.norm_out = GroupNorm(block_in)
         self.conv_out = Conv2d(block_in, 2 * z_channels if double_z else z_channels, 3, 1, 1)
+        if os.environ.get("DCVIC_WINO_ENCODER", "1") != "0":
+            allow_winograd(self)
 
     def forward(self, x: Tensor) -> Tensor:
         h = self.conv_in(x)
