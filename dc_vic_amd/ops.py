@@ -65,7 +65,7 @@ def conv_kernel_name(variant: int) -> str:
     if variant == 9003:
         return "void conv3x3_dma_kernel<3, 3, 4, 96>(ConvKArgs)"
     if variant == 9100:
-        return "conv3x3_wino_kernel(ConvKArgs)"
+        return "void conv3x3_wino_kernel<0>(ConvKArgs)"
     if 7000 <= variant < 8000:                       # conv1x1.hip: 7000 + cls
         return f"void conv1x1_dma_kernel<{(128, 64, 32, 96)[variant - 7000]}>(ConvKArgs)"
     if 8500 <= variant < 9000:                       # conv_async16.hip: 8500 + cls*100 + P/32 (tiles in units of 16)
