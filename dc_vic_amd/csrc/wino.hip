@@ -16,8 +16,9 @@
 //     V image of the NEXT stage while the MFMAs of the current stage run;
 //   * wave w = (co group cg = w % 4 of 16 channels, tile half th = w / 4 of 32 tiles) owns ALL 16 Winograd positions of its
 //     16 x 32 block: per position two `v_mfma_f32_16x16x4_f32` accumulators (128 accumulator registers per lane), fed by
-//     ONE ds_read_b64 (U: both k-steps) and ONE ds_read_b128 (V: two 16-tile blocks x both k-steps) per position --
-//     U slab word ((cg*4 + k)*16 + m)*2 + ks, V slab word ((th*4 + k)*16 + n)*4 + blk*2 + ks hold channel 4ks + k;
+//     ONE ds_read_b128 per position pair (U: two positions x both k-steps) and ONE ds_read_b128 per position (V: two
+//     16-tile blocks x both k-steps) -- U pair-slab word ((cg*4 + k)*16 + m)*4 + pq*2 + ks, V slab word
+//     ((th*4 + k)*16 + n)*4 + blk*2 + ks hold channel 4ks + k;
 //   * since a lane then holds the same (co, tile) element of all 16 positions, the output transform A^T M A runs in
 //     registers: no LDS exchange and no barrier after the last stage; bias -> act -> (+res) -> float2 stores.
 // LDS: 2 x 12 KiB raw patch + 2 x 32 KiB U + 2 x 32 KiB V + bias row = 152.25 KiB: one workgroup per CU.
@@ -58,16 +59,18 @@ __device__ __forceinline__ double wino_u(const float* g, int a, int b) {
     return s;
 }
 
-// packed[cotile][chunk][p 16][cg 4][k 4][m 16][ks 2]  <-  w[Cout][Cin][3][3]   (fp64 transform, rounded once)
+// packed[cotile][chunk][pair 8][cg 4][k 4][m 16][pq 2][ks 2]  <-  w[Cout][Cin][3][3]   (fp64 transform, rounded once);
+// position p = 2 pair + pq, channel 4 ks + k, output channel 16 cg + m
 __global__ void wino_pack_kernel(const float* __restrict__ w, float* __restrict__ wp, int Cin, int Cout, int n_chunks, long long total) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= total) return;
     long long r = i;
     const int ks = r & 1; r >>= 1;
+    const int pq = r & 1; r >>= 1;
     const int m = r & 15; r >>= 4;
     const int k = r & 3; r >>= 2;
     const int cg = r & 3; r >>= 2;
-    const int p = r & 15; r >>= 4;
+    const int p = 2 * (int)(r & 7) + pq; r >>= 3;
     const int chunk = (int)(r % n_chunks);
     const int cotile = (int)(r / n_chunks);
     const int co = cotile * WN_CO + cg * 16 + m, ci = chunk * KC + 4 * ks + k;
@@ -159,7 +162,7 @@ __global__ __launch_bounds__(WN_THREADS, 2) void conv3x3_wino_kernel(const ConvK
     const unsigned t_dst = 4u * (unsigned)(WN_OFF_V + ((t_th * 4 + t_k) * 16 + t_n) * 4 + t_blk * 2 + t_ks);
     // ---- MFMA operands: wave -> (cg = co group, th = tile half)
     const int cg = wave & 3, th = wave >> 2;
-    const unsigned op_u = 4u * (unsigned)(WN_OFF_U + cg * 128 + lane * 2);   // this lane's float2 of position 0
+    const unsigned op_u = 4u * (unsigned)(WN_OFF_U + cg * 256 + lane * 4);   // this lane's float4 of position pair 0
     const unsigned op_v = 4u * (unsigned)(WN_OFF_V + th * 256 + lane * 4);   // this lane's float4 of position 0
 
     f32x4 acc[16][2];                                             // [position][16-tile block]
@@ -197,20 +200,19 @@ __global__ __launch_bounds__(WN_THREADS, 2) void conv3x3_wino_kernel(const ConvK
         tv[4 * a + 2] = td[a][2] - td[a][1];
         tv[4 * a + 3] = td[a][1] - td[a][3];
     };
-    auto t_store = [&](auto p_, unsigned vaddr) {
+    auto t_store = [&](auto p_, unsigned vaddr) {                 // positions 2p and 2p + 1 (slabs 2 KiB apart = 8 x 64 dwords)
         constexpr int p = decltype(p_)::value;
-        const float val = tv[p];                                  // (asm operands inside a generic lambda do not capture)
-        asm volatile("ds_write_b32 %0, %1 offset:%2" :: "v"(vaddr), "v"(val), "n"(4 * 512 * p) : "memory");
+        const float v0 = tv[2 * p], v1 = tv[2 * p + 1];           // (asm operands inside a generic lambda do not capture)
+        asm volatile("ds_write2st64_b32 %0, %1, %2 offset0:%3 offset1:%4" :: "v"(vaddr), "v"(v0), "v"(v1), "n"(16 * p), "n"(16 * p + 8) : "memory");
     };
-    f32x2 opA[2][2];                                              // [set = pair parity][position inside the pair]
-    f32x4 opB[2][2];
+    f32x4 opA[2];                                                 // [set = pair parity]: (position 2j: ks 0, 1 | position 2j + 1: ks 0, 1)
+    f32x4 opB[2][2];                                              // [set][position inside the pair]: (blk 0: ks 0, 1 | blk 1: ks 0, 1)
     auto op_load = [&](auto j_, unsigned ua, unsigned va) {       // operands of positions 2j and 2j + 1
         constexpr int j = decltype(j_)::value;
-        f32x2 &a0 = opA[j & 1][0], &a1 = opA[j & 1][1];
+        f32x4 &a = opA[j & 1];
         f32x4 &b0 = opB[j & 1][0], &b1 = opB[j & 1][1];
-        asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(a0) : "v"(ua), "n"(4 * 512 * (2 * j)));
+        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(a) : "v"(ua), "n"(4 * 1024 * j));
         asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(b0) : "v"(va), "n"(4 * 512 * (2 * j)));
-        asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(a1) : "v"(ua), "n"(4 * 512 * (2 * j + 1)));
         asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(b1) : "v"(va), "n"(4 * 512 * (2 * j + 1)));
     };
     auto dma_x = [&](auto s_, int buf) {
@@ -254,28 +256,29 @@ __global__ __launch_bounds__(WN_THREADS, 2) void conv3x3_wino_kernel(const ConvK
     const int act = K.act;
     const bool has_bias = K.bias != nullptr, has_res = K.res != nullptr;
     auto tile_epilogue = [&](int cotile, int n, int oy0, int ox0, int par) __attribute__((always_inline)) {
-        const int ox = ox0 + 2 * tx;
-        const bool in_x = ox < K.W;
+        // Lanes tx and tx ^ 1 hold the 2x2 outputs of two horizontally adjacent tiles: they swap one row each (DPP quad_perm
+        // [1,0,3,2]) so that the even lane owns FOUR consecutive columns of the upper row and the odd lane of the lower row --
+        // one 16-byte store (and residual load) per lane and channel instead of two 8-byte ones (VMEM instructions are the
+        // expensive part of this kernel's side work).
+        const bool odd = tx & 1;
+        const int ox = ox0 + 2 * (tx & ~1);
+        const bool in_x = ox < K.W;                               // W % 4 == 0: all four columns or none
         const int co0 = cotile * WN_CO + cg * 16 + 4 * lq;
         float bv[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) bv[r] = has_bias ? sbias[par * WN_CO + cg * 16 + 4 * lq + r] : 0.f;
         dcvic_static_for<0, 2>([&](auto blk_) {
             constexpr int blk = decltype(blk_)::value;
-            const int oy = oy0 + 2 * (2 * th + blk);
-            const bool in_y0 = oy < K.H, in_y1 = oy + 1 < K.H;
+            const int oy = oy0 + 2 * (2 * th + blk) + (odd ? 1 : 0);
+            const bool live = in_x && oy < K.H;
             const long long pix = (long long)oy * K.W + ox;
             float* const ob = K.out + (long long)n * K.out_bs + pix;
             const float* const rb = has_res ? K.res + (long long)n * K.res_bs + pix : nullptr;
-            f32x2 r0[4], r1[4];
+            f32x4 rv[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                r0[r] = f32x2{0.f, 0.f}; r1[r] = f32x2{0.f, 0.f};
-                const int co = co0 + r;
-                if (has_res && in_x && co < K.Cout) {
-                    if (in_y0) r0[r] = *reinterpret_cast<const f32x2*>(rb + (long long)co * HW);
-                    if (in_y1) r1[r] = *reinterpret_cast<const f32x2*>(rb + (long long)co * HW + K.W);
-                }
+                rv[r] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (has_res && live && co0 + r < K.Cout) rv[r] = *reinterpret_cast<const f32x4*>(rb + (long long)(co0 + r) * HW);
             }
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -287,14 +290,13 @@ __global__ __launch_bounds__(WN_THREADS, 2) void conv3x3_wino_kernel(const ConvK
                 }
                 float y00 = s0[0] + s0[1] + s0[2], y01 = s0[1] - s0[2] - s0[3];
                 float y10 = s1[0] + s1[1] + s1[2], y11 = s1[1] - s1[2] - s1[3];
-                const int co = co0 + r;
-                if (co < K.Cout && in_x) {
-                    y00 += bv[r]; y01 += bv[r]; y10 += bv[r]; y11 += bv[r];
-                    y00 = dcvic_act(y00, act); y01 = dcvic_act(y01, act); y10 = dcvic_act(y10, act); y11 = dcvic_act(y11, act);
-                    const long long co_off = (long long)co * HW;
-                    if (in_y0) *reinterpret_cast<f32x2*>(ob + co_off) = f32x2{y00 + r0[r][0], y01 + r0[r][1]};
-                    if (in_y1) *reinterpret_cast<f32x2*>(ob + co_off + K.W) = f32x2{y10 + r1[r][0], y11 + r1[r][1]};
-                }
+                y00 = dcvic_act(y00 + bv[r], act); y01 = dcvic_act(y01 + bv[r], act);
+                y10 = dcvic_act(y10 + bv[r], act); y11 = dcvic_act(y11 + bv[r], act);
+                const float g0 = odd ? y00 : y10, g1 = odd ? y01 : y11;            // what the neighbour needs from this lane
+                const float n0 = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, g0), 0xB1, 0xF, 0xF, true));
+                const float n1 = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, g1), 0xB1, 0xF, 0xF, true));
+                const f32x4 o = odd ? f32x4{n0, n1, y10, y11} : f32x4{y00, y01, n0, n1};
+                if (live && co0 + r < K.Cout) *reinterpret_cast<f32x4*>(ob + (long long)(co0 + r) * HW) = o + rv[r];
             }
         });
 #pragma unroll
@@ -328,7 +330,7 @@ __global__ __launch_bounds__(WN_THREADS, 2) void conv3x3_wino_kernel(const ConvK
     WN_WAIT_LDS();
     dcvic_static_for<0, 4>([&](auto c_) { t_compute(c_); });
     dcvic_static_for<0, 4>([&](auto a_) { t_rows(a_); });
-    dcvic_static_for<0, 16>([&](auto p_) { t_store(p_, t_dst); });
+    dcvic_static_for<0, 8>([&](auto p_) { t_store(p_, t_dst); });
     WN_WAIT_LDS();
     __syncthreads();
     WN_FENCE();
@@ -361,7 +363,7 @@ __global__ __launch_bounds__(WN_THREADS, 2) void conv3x3_wino_kernel(const ConvK
             WN_FENCE();
             dcvic_static_for<0, 8>([&](auto i_) {
                 constexpr int i = decltype(i_)::value, pq = i >> 2, ks = (i >> 1) & 1, blk = i & 1, pp = 2 * j + pq;
-                acc[pp][blk] = __builtin_amdgcn_mfma_f32_16x16x4f32(opA[j & 1][pq][ks], opB[j & 1][pq][blk * 2 + ks], acc[pp][blk], 0, 0, 0);
+                acc[pp][blk] = __builtin_amdgcn_mfma_f32_16x16x4f32(opA[j & 1][pq * 2 + ks], opB[j & 1][pq][blk * 2 + ks], acc[pp][blk], 0, 0, 0);
                 WN_FENCE();
                 // slot sl = 8j + i.  DMA pieces one every 4th slot (all eight waves run this schedule in step: ten pieces in ten
                 // consecutive slots put 80 VMEM instructions into the CU's address unit at once and stalled the issuing waves --
@@ -372,7 +374,7 @@ __global__ __launch_bounds__(WN_THREADS, 2) void conv3x3_wino_kernel(const ConvK
                 if constexpr (!(DBG & 2) && more1 && j == 2 && (i & 3) >= 2) t_load(std::integral_constant<int, (i >> 2) * 2 + (i & 1)>{}, xaddr);
                 if constexpr (!(DBG & 2) && more1 && j == 3 && (i & 3) >= 2) t_compute(std::integral_constant<int, (i >> 2) * 2 + (i & 1)>{});
                 if constexpr (!(DBG & 2) && more1 && j == 4 && (i & 3) >= 2) t_rows(std::integral_constant<int, (i >> 2) * 2 + (i & 1)>{});
-                if constexpr (!(DBG & 2) && more1 && (j == 5 || j == 6)) t_store(std::integral_constant<int, 8 * (j - 5) + i>{}, vaddr);
+                if constexpr (!(DBG & 2) && more1 && (j == 5 || j == 6) && (i & 1)) t_store(std::integral_constant<int, 4 * (j - 5) + (i >> 1)>{}, vaddr);
                 WN_FENCE();
             });
         });
@@ -430,10 +432,10 @@ extern "C" int dcvic_conv3x3_wino_f32(int Cin, int Cout, const float* packed, co
     DCVIC_CHECK_ARG((io->W & 3) == 0, "conv3x3_wino: width must be a multiple of 4");
     DCVIC_CHECK_ARG(!io->aff_scale && !io->aff_shift && !io->init, "conv3x3_wino: affine / init epilogues are not supported");
     DCVIC_CHECK_ARG((long long)io->H * io->W * KC < (1ll << 31), "conv3x3_wino: plane too large");
-    DCVIC_CHECK_ARG(io->out_batch_stride >= (long long)Cout * io->H * io->W && (io->out_batch_stride & 1) == 0 &&
-                    (reinterpret_cast<uintptr_t>(io->out) & 7) == 0, "conv3x3_wino: output view must be 8-byte aligned");
-    DCVIC_CHECK_ARG(!io->res || (io->res_batch_stride >= (long long)Cout * io->H * io->W && (io->res_batch_stride & 1) == 0 &&
-                                 (reinterpret_cast<uintptr_t>(io->res) & 7) == 0), "conv3x3_wino: residual view must be 8-byte aligned");
+    DCVIC_CHECK_ARG(io->out_batch_stride >= (long long)Cout * io->H * io->W && (io->out_batch_stride & 3) == 0 &&
+                    (reinterpret_cast<uintptr_t>(io->out) & 15) == 0, "conv3x3_wino: output view must be 16-byte aligned");
+    DCVIC_CHECK_ARG(!io->res || (io->res_batch_stride >= (long long)Cout * io->H * io->W && (io->res_batch_stride & 3) == 0 &&
+                                 (reinterpret_cast<uintptr_t>(io->res) & 15) == 0), "conv3x3_wino: residual view must be 16-byte aligned");
     ConvKArgs K;
     memset(&K, 0, sizeof(K));
     K.Cin = Cin; K.Cout = Cout; K.T = 9; K.stride = 1;

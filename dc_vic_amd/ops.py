@@ -289,7 +289,8 @@ class ConvPlan:
             if sc.shape[0] not in (1, N):
                 raise ValueError("conv affine batch must be 1 or N")
         st = _stream()
-        if self.wino and WINO_ENABLED and init is None and affine is None and (self.wino == "force" or self._wino_ok(srcs, N, H, W)):
+        if self.wino and WINO_ENABLED and init is None and affine is None and (self.wino == "force" or self._wino_ok(srcs, N, H, W)) \
+                and out.data_ptr() % 16 == 0 and _bs(out) % 4 == 0 and (res is None or (res.data_ptr() % 16 == 0 and _bs(res) % 4 == 0)):
             if self._wino_pack is None:
                 nbytes = lib().dcvic_wino_packed_bytes(self.Cin, self.Cout)
                 self._wino_pack = torch.empty(nbytes // 4, dtype=torch.float32, device=self._w.device)

@@ -143,7 +143,7 @@ int dcvic_conv2d_f32(const dcvic_conv_desc* d, const float* packed, const dcvic_
  *   ldm/modules/diffusionmodules/model.py:82-141 (ResnetBlock convs), :462-568 (Decoder);
  *   src/models/layer/codeformer_layers.py:20-67; src/models/subnet/vq_fusion_module.py:78-126.
  * Same io contract as dcvic_conv2d_f32 restricted to: Hout = Hfull = H, Wout = Wfull = W (W % 4 == 0), no scatter, every
- * source a multiple of 8 channels and 16-byte aligned, epilogue bias -> act -> (+res) (no affine, no init), out / res 8-byte aligned.
+ * source a multiple of 8 channels and 16-byte aligned, epilogue bias -> act -> (+res) (no affine, no init), out / res 16-byte aligned.
  * Weights: w[Cout][Cin][3][3] -> G g G^T in fp64, rounded once, packed per (64-channel tile, 8-channel chunk) as the
  * kernel's LDS image.  Deterministic and batch-invariant (fixed tile grid, ordered fmaf chains). */
 size_t dcvic_wino_packed_bytes(int Cin, int Cout);
