@@ -369,12 +369,19 @@ __global__ __launch_bounds__(WN_THREADS, 2) void conv3x3_wino_kernel(const ConvK
                 // consecutive slots put 80 VMEM instructions into the CU's address unit at once and stalled the issuing waves --
                 // measured 16 % of the kernel), U first (needed right after the barrier), then X; transform work after them.
                 constexpr int sl = 8 * j + i;
-                if constexpr (!(DBG & 36) && more1 && (sl & 3) == 1 && sl < 16) dma_u(std::integral_constant<int, sl / 4>{}, nxt);
-                if constexpr (!(DBG & 20) && more2 && (sl & 3) == 1 && sl >= 16 && sl < 24) dma_x(std::integral_constant<int, sl / 4 - 4>{}, cur);
-                if constexpr (!(DBG & 2) && more1 && j == 2 && (i & 3) >= 2) t_load(std::integral_constant<int, (i >> 2) * 2 + (i & 1)>{}, xaddr);
-                if constexpr (!(DBG & 2) && more1 && j == 3 && (i & 3) >= 2) t_compute(std::integral_constant<int, (i >> 2) * 2 + (i & 1)>{});
-                if constexpr (!(DBG & 2) && more1 && j == 4 && (i & 3) >= 2) t_rows(std::integral_constant<int, (i >> 2) * 2 + (i & 1)>{});
-                if constexpr (!(DBG & 2) && more1 && (j == 5 || j == 6) && (i & 1)) t_store(std::integral_constant<int, 4 * (j - 5) + (i >> 1)>{}, vaddr);
+                auto fillers = [&]() __attribute__((always_inline)) {
+                    if constexpr (!(DBG & 36) && more1 && (sl & 3) == 1 && sl < 16) dma_u(std::integral_constant<int, sl / 4>{}, nxt);
+                    if constexpr (!(DBG & 20) && more2 && (sl & 3) == 1 && sl >= 16 && sl < 24) dma_x(std::integral_constant<int, sl / 4 - 4>{}, cur);
+                    if constexpr (!(DBG & 2) && more1 && j == 2 && (i & 3) >= 2) t_load(std::integral_constant<int, (i >> 2) * 2 + (i & 1)>{}, xaddr);
+                    if constexpr (!(DBG & 2) && more1 && j == 3 && (i & 3) >= 2) t_compute(std::integral_constant<int, (i >> 2) * 2 + (i & 1)>{});
+                    if constexpr (!(DBG & 2) && more1 && j == 4 && (i & 3) >= 2) t_rows(std::integral_constant<int, (i >> 2) * 2 + (i & 1)>{});
+                    if constexpr (!(DBG & 2) && more1 && (j == 5 || j == 6) && (i & 1)) t_store(std::integral_constant<int, 4 * (j - 5) + (i >> 1)>{}, vaddr);
+                };
+                if constexpr (DBG & 128) {          // experiment: waves 4..7 do the side work of a SIMD twice, waves 0..3 none
+                    if (wave >= 4) { fillers(); WN_FENCE(); fillers(); }
+                } else {
+                    fillers();
+                }
                 WN_FENCE();
             });
         });
@@ -460,7 +467,7 @@ extern "C" int dcvic_conv3x3_wino_f32(int Cin, int Cout, const float* packed, co
     const int dbg = K.TG >> 4;
     K.TG &= 15;
     auto kern = dbg == 1 ? conv3x3_wino_kernel<1> : dbg == 2 ? conv3x3_wino_kernel<2> : dbg == 4 ? conv3x3_wino_kernel<4> : dbg == 8 ? conv3x3_wino_kernel<8> :
-                dbg == 6 ? conv3x3_wino_kernel<6> : dbg == 16 ? conv3x3_wino_kernel<16> : dbg == 32 ? conv3x3_wino_kernel<32> : dbg == 64 ? conv3x3_wino_kernel<64> : conv3x3_wino_kernel<0>;
+                dbg == 6 ? conv3x3_wino_kernel<6> : dbg == 16 ? conv3x3_wino_kernel<16> : dbg == 32 ? conv3x3_wino_kernel<32> : dbg == 64 ? conv3x3_wino_kernel<64> : dbg == 128 ? conv3x3_wino_kernel<128> : conv3x3_wino_kernel<0>;
     if (dcvic_first_use_on_device(attr_mask) || dbg)
         hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     // persistent grid: one workgroup per CU (152 KiB of LDS each), a multiple of the 8 XCDs; each walks its share of the tiles
