@@ -20,6 +20,11 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wno-unused-val
          f"-I{os.path.join(ROOT, 'include')}", f"-I{HERE}"]
 
 
+# per-file extras.  wino.hip: hipcc's SLP vectoriser packs the input transform's adds into v_pk_add_f32, which costs MFMA issue
+# time beside the matrix pipe (MI355X_MICROARCH "packed f32 VALU ... an anti-lever beside MFMAs")
+EXTRA_FLAGS = {"wino.hip": ["-fno-slp-vectorize"]}
+
+
 def _hipcc() -> str:
     for c in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", "hipcc"):
         if c and (os.path.isabs(c) and os.path.exists(c) or not os.path.isabs(c)):
@@ -39,7 +44,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
         objs.append(obj)
         if force or not os.path.exists(obj) or os.path.getmtime(obj) < max(os.path.getmtime(src), hdr_m):
             lang = ["-x", "hip"] if s.endswith(".hip") else []
-            jobs.append([_hipcc(), *FLAGS, *lang, "-c", src, "-o", obj])
+            jobs.append([_hipcc(), *FLAGS, *EXTRA_FLAGS.get(s, []), *lang, "-c", src, "-o", obj])
 
     def run(cmd):
         if verbose:
