@@ -136,7 +136,10 @@ def _dgrad_plan(mod) -> ops.ConvPlan:
     if mod.asym_pad:
         raise NotImplementedError("the ldm Downsample conv is encoder-side only (never differentiated)")
     if s == 1:
-        return ops.ConvPlan(w.flip(2, 3).transpose(0, 1).contiguous(), None, "conv", pad=(k - 1 - p, k - 1 - p))
+        plan = ops.ConvPlan(w.flip(2, 3).transpose(0, 1).contiguous(), None, "conv", pad=(k - 1 - p, k - 1 - p))
+        # the data gradient of a Conv2d(k3, s1, p1) is again one: Winograd wherever the forward layer opted in (layers.allow_winograd)
+        plan.wino = bool(getattr(mod, "wino", False)) and (k, p) == (3, 1)
+        return plan
     if (k, s, p) == (4, 2, 1):
         # adjoint = ConvTranspose2d(k4, s2, p1): output row 2m+py takes (input row, ky) in {(m-1, 3), (m, 1)} for py = 0 and
         # {(m, 2), (m+1, 0)} for py = 1 (oy = 2 iy - 1 + ky); four 2x2 sub-pixel convolutions
@@ -171,6 +174,7 @@ def conv(ctx: Ctx, x: Var, mod, act: int = ops.ACT_NONE) -> Var:
                 plan = ops.ConvPlan(mod.weight, mod.bias, "conv")
             else:
                 plan = ops.ConvPlan(mod.weight, mod.bias, "conv", stride=mod.stride, pad=(mod.padding, mod.padding))
+                plan.wino = bool(getattr(mod, "wino", False))    # (the SFT fusion blocks train; their 3x3 convs stay on Winograd)
         else:
             plan = mod._get_plan()
     y = plan(xin, act=act)
