@@ -37,3 +37,15 @@ def test_error_reporting_without_gpu():
     assert L.dcvic_convT_phase_desc(C.byref(d), 192, 192, 5, 0, 0) == 0 and d.T == 9
     assert L.dcvic_convT_phase_desc(C.byref(d), 192, 192, 5, 1, 1) == 0 and d.T == 4
     assert L.dcvic_convT_phase_desc(C.byref(d), 192, 192, 5, 0, 1) == 0 and d.T == 6
+
+
+def test_wino_packed_bytes_host_formula():
+    """dcvic_wino_packed_bytes is a host-side size query (no GPU): one 32 KiB slab (16 positions x 8 channels x 64 output
+    channels, fp32) per (64-channel tile, 8-channel chunk), both rounded up."""
+    import ctypes as C
+    from dc_vic_amd import _lib
+    L = _lib.lib()
+    L.dcvic_wino_packed_bytes.restype = C.c_size_t
+    for cin, cout in ((128, 128), (704, 512), (8, 64), (20, 96), (256, 3)):
+        assert L.dcvic_wino_packed_bytes(cin, cout) == ((cout + 63) // 64) * ((cin + 7) // 8) * 16 * 8 * 64 * 4
+    assert L.dcvic_wino_packed_bytes(0, 64) == 0
