@@ -79,8 +79,14 @@ __global__ void wino_pack_kernel(const float* __restrict__ w, float* __restrict_
     wp[i] = v;
 }
 
-// DBG (timing experiments, wrong results, DCVIC_WINO_DEBUG=16*DBG): 1 no stage barrier, 2 no transform, 4 no DMA, 8 no operand waits,
+// DBG: timing experiments with WRONG results, instantiated only in the diagnostic build (-DDCVIC_WINO_EXPERIMENTS,
+// tools/build_wino_experiments.sh -> tools/libdcvic_wino_exp.so, never in libdcvic_hip.so), selected by DCVIC_WINO_DEBUG=16*DBG: 1 no stage barrier, 2 no transform, 4 no DMA, 8 no operand waits,
 // 16 no X DMA, 32 no U DMA, 64 no vmcnt wait in front of the stage barrier
+#ifdef DCVIC_WINO_EXPERIMENTS
+#define WN_DBG_ARG(bit) (K.TG & (bit))     // 1: every X load from the cached zero source, 2: the same U slab every stage
+#else
+#define WN_DBG_ARG(bit) false
+#endif
 template <int DBG>
 __global__ __launch_bounds__(WN_THREADS, 2) void conv3x3_wino_kernel(const ConvKArgs K) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -124,7 +130,7 @@ __global__ __launch_bounds__(WN_THREADS, 2) void conv3x3_wino_kernel(const ConvK
         if (c >= K.srcC[0]) { c -= K.srcC[0]; si = 1; if (c >= K.srcC[1]) { c -= K.srcC[1]; si = 2; } }
         const float* base = K.src[si] + (long long)x_n * K.src_bs[si] + (long long)c * HW;
 #pragma unroll
-        for (int s = 0; s < WN_XSLOTS; ++s) xp[s] = (poff[s] >= 0 && !(K.TG & 1)) ? base + poff[s] : dcvic_wino_zero;
+        for (int s = 0; s < WN_XSLOTS; ++s) xp[s] = (poff[s] >= 0 && !WN_DBG_ARG(1)) ? base + poff[s] : dcvic_wino_zero;
         x_left = K.srcC[si] - c;
     };
     auto x_setup = [&](int b) __attribute__((always_inline)) {
@@ -262,7 +268,7 @@ __global__ __launch_bounds__(WN_THREADS, 2) void conv3x3_wino_kernel(const ConvK
             x_left -= KC;
             if (x_left > 0) {
 #pragma unroll
-                for (int sl = 0; sl < WN_XSLOTS; ++sl) xp[sl] += (poff[sl] >= 0 && !(K.TG & 1)) ? x_stride : 0ll;   // (padding lanes stay on the zero word)
+                for (int sl = 0; sl < WN_XSLOTS; ++sl) xp[sl] += (poff[sl] >= 0 && !WN_DBG_ARG(1)) ? x_stride : 0ll;   // (padding lanes stay on the zero word)
             } else {
                 x_rebase(x_next * KC);
             }
@@ -274,7 +280,7 @@ __global__ __launch_bounds__(WN_THREADS, 2) void conv3x3_wino_kernel(const ConvK
             u_b += J;
             if (u_b < xe) u_setup(u_b);
         } else {
-            if (!(K.TG & 2)) wp0 += WN_US;
+            if (!WN_DBG_ARG(2)) wp0 += WN_US;
         }
     };
 
@@ -518,7 +524,9 @@ extern "C" int dcvic_conv3x3_wino_f32(int Cin, int Cout, const float* packed, co
     K.out = io->out; K.out_bs = io->out_batch_stride; K.bias = io->bias; K.act = io->act;
     K.res = io->res; K.res_bs = io->res_batch_stride;
     K.wp = packed;
+#ifdef DCVIC_WINO_EXPERIMENTS
     { const char* e = getenv("DCVIC_WINO_DEBUG"); K.TG = e ? atoi(e) : 0; }   // timing experiments only (wrong results)
+#endif
     K.n_chunks = (Cin + KC - 1) / KC;
     K.n_cotiles = (Cout + WN_CO - 1) / WN_CO;
     K.tiles_y = (io->H + WN_TH - 1) / WN_TH;
@@ -527,11 +535,17 @@ extern "C" int dcvic_conv3x3_wino_f32(int Cin, int Cout, const float* packed, co
     DCVIC_CHECK_ARG(blocks < (1ll << 31), "conv3x3_wino: grid too large");
     K.nblocks = (int)blocks;
     static std::atomic<unsigned> attr_mask{0};
+#ifdef DCVIC_WINO_EXPERIMENTS
     const int dbg = K.TG >> 4;
     K.TG &= 15;
     auto kern = dbg == 1 ? conv3x3_wino_kernel<1> : dbg == 2 ? conv3x3_wino_kernel<2> : dbg == 4 ? conv3x3_wino_kernel<4> : dbg == 8 ? conv3x3_wino_kernel<8> :
                 dbg == 6 ? conv3x3_wino_kernel<6> : dbg == 16 ? conv3x3_wino_kernel<16> : dbg == 32 ? conv3x3_wino_kernel<32> : dbg == 64 ? conv3x3_wino_kernel<64> : dbg == 128 ? conv3x3_wino_kernel<128> : dbg == 256 ? conv3x3_wino_kernel<256> : conv3x3_wino_kernel<0>;
-    if (dcvic_first_use_on_device(attr_mask) || dbg)
+    const bool set_attr = dcvic_first_use_on_device(attr_mask) || dbg;
+#else
+    auto kern = conv3x3_wino_kernel<0>;
+    const bool set_attr = dcvic_first_use_on_device(attr_mask);
+#endif
+    if (set_attr)
         hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     // persistent grid: one workgroup per CU (152 KiB of LDS each), a multiple of the 8 XCDs; each walks its share of the tiles
     int grid = (dcvic_num_cu() / NXCD) * NXCD;
