@@ -185,18 +185,21 @@ __global__ __launch_bounds__(WN_THREADS, 2) void conv3x3_wino_kernel(const ConvK
     // visible to it as an LDS access, so the only vmcnt wait is the explicit one in front of the stage barrier.
 #define WN_FENCE() __builtin_amdgcn_sched_barrier(0)
 #define WN_WAIT_LDS() do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); WN_FENCE(); } while (0)
-    float td[4][4];                                               // raw 4x4 patch of the transform
-    auto t_load = [&](auto r_, unsigned xaddr) {                  // row r of the patch: two ds_read_b64
+    // raw 4x4 patch of the transform.  The asm loads write the very variables t_compute reads after the wait: a copy made
+    // between a load and the `s_waitcnt` would read the register before the LDS data has landed.
+    f32x2 tlo[4], thi[4];
+    float td[4][4];
+    auto t_load = [&](auto r_, unsigned xaddr) {                  // row r of the patch: two dword pairs
         constexpr int r = decltype(r_)::value;
-        f32x2 lo, hi;                                             // (odd dword offset: two dwords per read instead of one ds_read_b64)
+        f32x2 &lo = tlo[r], &hi = thi[r];                         // (odd dword offset: two dwords per read instead of one ds_read_b64)
         asm volatile("ds_read2_b32 %0, %1 offset0:%2 offset1:%3" : "=v"(lo) : "v"(xaddr), "n"(r * WN_PW), "n"(r * WN_PW + 1));
         asm volatile("ds_read2_b32 %0, %1 offset0:%2 offset1:%3" : "=v"(hi) : "v"(xaddr), "n"(r * WN_PW + 2), "n"(r * WN_PW + 3));
-        td[r][0] = lo[0]; td[r][1] = lo[1]; td[r][2] = hi[0]; td[r][3] = hi[1];
     };
     float tv[16];
     auto t_compute = [&](auto c_) {                               // column c of B^T d, then nothing else: rows are finished in t_rows
         constexpr int c = decltype(c_)::value;
-        const float d0 = td[0][c], d1 = td[1][c], d2 = td[2][c], d3 = td[3][c];
+        const float d0 = c < 2 ? tlo[0][c & 1] : thi[0][c & 1], d1 = c < 2 ? tlo[1][c & 1] : thi[1][c & 1];
+        const float d2 = c < 2 ? tlo[2][c & 1] : thi[2][c & 1], d3 = c < 2 ? tlo[3][c & 1] : thi[3][c & 1];
         td[0][c] = d0 - d2; td[1][c] = d1 + d2; td[2][c] = d2 - d1; td[3][c] = d1 - d3;
     };
     auto t_rows = [&](auto a_) {                                  // row a of (B^T d) B
@@ -474,6 +477,377 @@ __global__ __launch_bounds__(WN_THREADS, 2) void conv3x3_wino_kernel(const ConvK
     }
 #undef WN_FENCE
 #undef WN_WAIT_LDS
+}
+
+// ------------------------------------------------------------------------------------------------------------------------
+// Nearest-x2 upsample + Conv2d(k3, s1, p1) (ldm Upsample, model.py:42-57) as a STRUCTURED Winograd F(2x2, 3x3).
+// A 2x2 output tile aligned to the 2x2 blocks of the upsampled image sees input rows [a, b, b, c] (three low-resolution rows),
+// so B^T d = [a - b, 2b, 0, b - c]: the third transformed row (and column) is identically zero and only 9 of the 16 Winograd
+// positions carry data -- 9 multiplies per 4 outputs and input channel (2.25 per output; the four 2x2 sub-pixel phase
+// convolutions execute 4, the plain 3x3 sum 9).  The factors 2 move into the weights (U'[a][b] = U[A(a)][A(b)] * 2^[a=1] * 2^[b=1],
+// A = {0, 1, 3}: exact in fp32), which leaves V' = R d R^T with R = [[1,-1,0],[0,1,0],[0,1,-1]]: twelve subtractions per patch.
+// Same workgroup shape, persistent stage stream, LDS images, barrier protocol and register-only epilogue as conv3x3_wino_kernel;
+// the tile grid runs over the OUTPUT (8 x 32 pixels = 4 x 16 low-resolution pixels), the raw patch is 8 ch x 6 rows x six 16-byte
+// segments of the LOW-resolution map, a stage has 36 MFMAs per wave (positions 0..8 as pairs (0,1) .. (6,7), (8)).
+#define WU_NPOS 9
+#define WU_PW 24
+#define WU_PLANE 144
+#define WU_SEGS 288
+#define WU_US 5120          // floats of a stage's U slab: 5 pair slabs x 1024 (the tenth position is zero padding)
+
+// packed[cotile][chunk][pair 5][cg 4][k 4][m 16][pq 2][ks 2]  <-  w[Cout][Cin][3][3]
+__global__ void wino_ups_pack_kernel(const float* __restrict__ w, float* __restrict__ wp, int Cin, int Cout, int n_chunks, long long total) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    long long r = i;
+    const int ks = r & 1; r >>= 1;
+    const int pq = r & 1; r >>= 1;
+    const int m = r & 15; r >>= 4;
+    const int k = r & 3; r >>= 2;
+    const int cg = r & 3; r >>= 2;
+    const int pair = (int)(r % 5); r /= 5;
+    const int chunk = (int)(r % n_chunks);
+    const int cotile = (int)(r / n_chunks);
+    const int p9 = 2 * pair + pq;
+    const int co = cotile * WN_CO + cg * 16 + m, ci = chunk * KC + 4 * ks + k;
+    float v = 0.f;
+    if (p9 < WU_NPOS && co < Cout && ci < Cin) {
+        const int a = p9 / 3, b = p9 - 3 * a;
+        const int A[3] = {0, 1, 3};
+        v = (float)(wino_u(w + ((long long)co * Cin + ci) * 9, A[a], A[b]) * (a == 1 ? 2.0 : 1.0) * (b == 1 ? 2.0 : 1.0));
+    }
+    wp[i] = v;
+}
+
+__global__ __launch_bounds__(WN_THREADS, 2) void conv3x3_wino_ups_kernel(const ConvKArgs K) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const long long HW = (long long)K.H * K.W;                    // low-resolution input plane
+    const long long HWo = (long long)K.Hfull * K.Wfull;           // output plane
+    const int S = K.n_chunks;
+    const long long x_stride = (long long)KC * HW;
+    int xe, first;
+    const int J = (int)gridDim.x / NXCD;
+    {
+        const int nb = K.nblocks, q = nb / NXCD, r = nb % NXCD, x = (int)blockIdx.x % NXCD;
+        const int xs = x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q;
+        xe = xs + (x < r ? q + 1 : q);
+        first = xs + (int)blockIdx.x / NXCD;
+    }
+    if (first >= xe) return;
+    const int total = ((xe - first + J - 1) / J) * S;
+    auto decode = [&](int b, int& cotile, int& n, int& oy0, int& ox0) __attribute__((always_inline)) {
+        cotile = b % K.n_cotiles; b /= K.n_cotiles;
+        const int tile_x = b % K.tiles_x; b /= K.tiles_x;
+        const int tile_y = b % K.tiles_y; b /= K.tiles_y;
+        n = b; oy0 = tile_y * WN_TH; ox0 = tile_x * WN_TW;          // OUTPUT coordinates
+    };
+    // ---- raw low-resolution patch: segment e = tid of [8 ch][6 rows][6 segments] (waves 0..4)
+    const float* xp;
+    int poff;
+    int x_left = 0, x_n = 0, x_b = first, x_next = 0;
+    auto x_rebase = [&](int c) __attribute__((always_inline)) {
+        int si = 0;
+        if (c >= K.srcC[0]) { c -= K.srcC[0]; si = 1; if (c >= K.srcC[1]) { c -= K.srcC[1]; si = 2; } }
+        const float* base = K.src[si] + (long long)x_n * K.src_bs[si] + (long long)c * HW;
+        xp = poff >= 0 ? base + poff : dcvic_wino_zero;
+        x_left = K.srcC[si] - c;
+    };
+    auto x_setup = [&](int b) __attribute__((always_inline)) {
+        int cot, oy0, ox0;
+        decode(b, cot, x_n, oy0, ox0);
+        int o = -1;
+        if (tid < WU_SEGS) {
+            const int k = tid / 36, r = tid - k * 36;
+            const int py = r / 6, seg = r - py * 6;
+            const int iy = oy0 / 2 - 1 + py, ix = ox0 / 2 - 4 + 4 * seg;
+            if (iy >= 0 && iy < K.H && ix >= 0 && ix < K.W) o = (int)(k * HW) + iy * K.W + ix;
+        }
+        poff = o;
+        x_rebase(0);
+    };
+    x_setup(first);
+    const float* wp0;
+    int u_b = first, u_next = 0;
+    auto u_setup = [&](int b) __attribute__((always_inline)) {
+        wp0 = K.wp + (long long)(b % K.n_cotiles) * S * (long long)WU_US + 4 * tid;
+    };
+    u_setup(first);
+    // ---- input transform: wave -> (th, k); lane -> (n, blk, ks); channel 4ks + k, low-resolution pixel (row 2th + blk, column n)
+    const int t_th = wave >> 2, t_k = wave & 3;
+    const int t_n = lane & 15, t_blk = (lane >> 4) & 1, t_ks = lane >> 5;
+    const unsigned t_src = 4u * (unsigned)((4 * t_ks + t_k) * WU_PLANE + (2 * t_th + t_blk) * WU_PW + t_n + 3);
+    const unsigned t_dst = 4u * (unsigned)(WN_OFF_V + ((t_th * 4 + t_k) * 16 + t_n) * 4 + t_blk * 2 + t_ks);
+    const int cg = wave & 3, th = wave >> 2;
+    const unsigned op_u = 4u * (unsigned)(WN_OFF_U + cg * 256 + lane * 4);
+    const unsigned op_v = 4u * (unsigned)(WN_OFF_V + th * 256 + lane * 4);
+    f32x4 acc[WU_NPOS][2];
+#pragma unroll
+    for (int i = 0; i < WU_NPOS; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[i][j][r] = 0.f;
+#define WN_FENCE() __builtin_amdgcn_sched_barrier(0)
+#define WN_WAIT_LDS() do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); WN_FENCE(); } while (0)
+    // (the asm loads write the very variables the transform reads after the wait: a copy made between the load and the
+    // `s_waitcnt` would read the register before the LDS data has landed)
+    f32x2 tlo[3];
+    float tc2[3];
+    float td[3][3], tv[10];
+    auto t_load = [&](auto r_, unsigned xaddr) {
+        constexpr int r = decltype(r_)::value;
+        f32x2& lo = tlo[r];
+        float& c2 = tc2[r];
+        asm volatile("ds_read2_b32 %0, %1 offset0:%2 offset1:%3" : "=v"(lo) : "v"(xaddr), "n"(r * WU_PW), "n"(r * WU_PW + 1));
+        asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(c2) : "v"(xaddr), "n"(4 * (r * WU_PW + 2)));
+    };
+    auto t_cols = [&]() {                                         // R d: rows [d0 - d1, d1, d1 - d2]
+        const float d0[3] = {tlo[0][0], tlo[0][1], tc2[0]}, d1[3] = {tlo[1][0], tlo[1][1], tc2[1]}, d2[3] = {tlo[2][0], tlo[2][1], tc2[2]};
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { td[0][c] = d0[c] - d1[c]; td[1][c] = d1[c]; td[2][c] = d1[c] - d2[c]; }
+    };
+    auto t_rows = [&]() {                                         // (R d) R^T
+#pragma unroll
+        for (int a = 0; a < 3; ++a) { tv[3 * a] = td[a][0] - td[a][1]; tv[3 * a + 1] = td[a][1]; tv[3 * a + 2] = td[a][1] - td[a][2]; }
+        tv[9] = 0.f;
+    };
+    auto t_store = [&](auto p_, unsigned vaddr) {                 // positions 2p, 2p + 1; p = 4: position 8 alone
+        constexpr int p = decltype(p_)::value;
+        const float v0 = tv[2 * p], v1 = tv[2 * p + 1];
+        if constexpr (p < 4) asm volatile("ds_write2st64_b32 %0, %1, %2 offset0:%3 offset1:%4" :: "v"(vaddr), "v"(v0), "v"(v1), "n"(16 * p), "n"(16 * p + 8) : "memory");
+        else asm volatile("ds_write_b32 %0, %1 offset:%2" :: "v"(vaddr), "v"(v0), "n"(4 * 512 * 8) : "memory");
+    };
+    f32x4 opA[2];
+    f32x4 opB[2][2];
+    // operand register set of pair j in a stage of parity PAR: (j + PAR) & 1.  Five pairs per stage: the last pair of a stage and
+    // the first pair of the next one (requested behind the barrier, before the last pair's MFMAs) must not share a set, so the
+    // sets swap roles every stage and the stage body is instantiated for both parities.
+    auto op_load = [&](auto j_, auto set_, unsigned ua, unsigned va) {
+        constexpr int j = decltype(j_)::value, set = decltype(set_)::value;
+        f32x4 &a = opA[set];
+        f32x4 &b0 = opB[set][0], &b1 = opB[set][1];
+        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(a) : "v"(ua), "n"(4 * 1024 * j));
+        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(b0) : "v"(va), "n"(4 * 512 * (2 * j)));
+        if constexpr (2 * j + 1 < WU_NPOS) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(b1) : "v"(va), "n"(4 * 512 * (2 * j + 1)));
+    };
+    auto dma_x = [&](int buf) {
+        if (wave < 5) __builtin_amdgcn_global_load_lds(reinterpret_cast<const float4*>(xp), (lds_ptr_t)(smem + buf * WN_XS + wave * 64 * 4), 16, 0, 0);
+    };
+    auto dma_u = [&](auto j_, int buf) {
+        constexpr int j = decltype(j_)::value;
+        if (j < 2 || wave < 4)
+            __builtin_amdgcn_global_load_lds(reinterpret_cast<const float4*>(wp0 + j * (4 * WN_THREADS)), (lds_ptr_t)(smem + WN_OFF_U + buf * WN_US + (wave * 64 + j * WN_THREADS) * 4), 16, 0, 0);
+    };
+    auto x_advance = [&]() __attribute__((always_inline)) {
+        if (++x_next == S) {
+            x_next = 0; x_b += J;
+            if (x_b < xe) x_setup(x_b);
+        } else {
+            x_left -= KC;
+            if (x_left > 0) xp += poff >= 0 ? x_stride : 0ll;
+            else x_rebase(x_next * KC);
+        }
+    };
+    auto u_advance = [&]() __attribute__((always_inline)) {
+        if (++u_next == S) { u_next = 0; u_b += J; if (u_b < xe) u_setup(u_b); }
+        else wp0 += WU_US;
+    };
+    float* const sbias = smem + WN_OFF_BIAS;
+    const int tx = lane & 15, lq = lane >> 4;
+    const int act = K.act;
+    const bool has_bias = K.bias != nullptr, has_res = K.res != nullptr;
+    auto tile_epilogue = [&](int cotile, int n, int oy0, int ox0, int par) __attribute__((always_inline)) {
+        const bool odd = tx & 1;
+        const int ox = ox0 + 2 * (tx & ~1);
+        const bool in_x = ox < K.Wfull;
+        const int co0 = cotile * WN_CO + cg * 16 + 4 * lq;
+        float bv[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) bv[r] = has_bias ? sbias[par * WN_CO + cg * 16 + 4 * lq + r] : 0.f;
+        dcvic_static_for<0, 2>([&](auto blk_) {
+            constexpr int blk = decltype(blk_)::value;
+            const int oy = oy0 + 2 * (2 * th + blk) + (odd ? 1 : 0);
+            const bool live = in_x && oy < K.Hfull;
+            const long long pix = (long long)oy * K.Wfull + ox;
+            float* const ob = K.out + (long long)n * K.out_bs + pix;
+            const float* const rb = has_res ? K.res + (long long)n * K.res_bs + pix : nullptr;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                f32x4 rv = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (has_res && live && co0 + r < K.Cout) rv = *reinterpret_cast<const f32x4*>(rb + (long long)(co0 + r) * HWo);
+                float s0[3], s1[3];                               // A^T M with the third Winograd row / column absent
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    s0[c] = acc[c][blk][r] + acc[3 + c][blk][r];
+                    s1[c] = acc[3 + c][blk][r] - acc[6 + c][blk][r];
+                }
+                float y00 = s0[0] + s0[1], y01 = s0[1] - s0[2];
+                float y10 = s1[0] + s1[1], y11 = s1[1] - s1[2];
+                y00 = dcvic_act(y00 + bv[r], act); y01 = dcvic_act(y01 + bv[r], act);
+                y10 = dcvic_act(y10 + bv[r], act); y11 = dcvic_act(y11 + bv[r], act);
+                const float g0 = odd ? y00 : y10, g1 = odd ? y01 : y11;
+                const float n0 = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, g0), 0xB1, 0xF, 0xF, true));
+                const float n1 = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, g1), 0xB1, 0xF, 0xF, true));
+                const f32x4 o = odd ? f32x4{n0, n1, y10, y11} : f32x4{y00, y01, n0, n1};
+                if (live && co0 + r < K.Cout) *reinterpret_cast<f32x4*>(ob + (long long)(co0 + r) * HWo) = o + rv;
+            }
+        });
+#pragma unroll
+        for (int i = 0; i < WU_NPOS; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[i][j][r] = 0.f;
+    };
+    auto stage_bias = [&](int b, int par) __attribute__((always_inline)) {
+        if (tid < WN_CO) sbias[par * WN_CO + tid] = has_bias ? K.bias[min((b % K.n_cotiles) * WN_CO + tid, K.Cout - 1)] : 0.f;
+    };
+    int c_b = first, c_chunk = 0, c_par = 0;
+    int c_cotile, c_n, c_oy0, c_ox0;
+    decode(first, c_cotile, c_n, c_oy0, c_ox0);
+    stage_bias(first, 0);
+    dma_x(0); x_advance();
+    dcvic_static_for<0, 3>([&](auto j_) { dma_u(j_, 0); });
+    u_advance();
+    if (total > 1) { dma_x(1); x_advance(); }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    WN_FENCE();
+    dcvic_static_for<0, 3>([&](auto r_) { t_load(r_, t_src); });
+    WN_WAIT_LDS();
+    t_cols(); t_rows();
+    dcvic_static_for<0, 5>([&](auto p_) { t_store(p_, t_dst); });
+    WN_WAIT_LDS();
+    __syncthreads();
+    WN_FENCE();
+    op_load(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, op_u, op_v);
+    auto run_stage = [&](auto more1_, auto more2_, auto par_, int g) __attribute__((always_inline)) {
+        constexpr bool more1 = decltype(more1_)::value, more2 = decltype(more2_)::value;
+        constexpr int PAR = decltype(par_)::value;
+        const int cur = g & 1, nxt = cur ^ 1;
+        const unsigned ua = op_u + (unsigned)(cur * WN_US * 4), va = op_v + (unsigned)(cur * WN_VS * 4);
+        const unsigned xaddr = t_src + (unsigned)(nxt * WN_XS * 4), vaddr = t_dst + (unsigned)(nxt * WN_VS * 4);
+        dcvic_static_for<0, 5>([&](auto j_) {
+            constexpr int j = decltype(j_)::value;
+            if constexpr (j < 4) {
+                WN_WAIT_LDS();
+                op_load(std::integral_constant<int, j + 1>{}, std::integral_constant<int, (j + 1 + PAR) & 1>{}, ua, va);
+            } else {
+                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+                __syncthreads();
+                WN_FENCE();
+                if constexpr (more1) op_load(std::integral_constant<int, 0>{}, std::integral_constant<int, PAR ^ 1>{}, op_u + (unsigned)(nxt * WN_US * 4), op_v + (unsigned)(nxt * WN_VS * 4));
+            }
+            WN_FENCE();
+            dcvic_static_for<0, 8>([&](auto i_) {
+                constexpr int i = decltype(i_)::value, pq = i >> 2, ks = (i >> 1) & 1, blk = i & 1, pp = 2 * j + pq;
+                if constexpr (pp < WU_NPOS) {
+                    acc[pp][blk] = __builtin_amdgcn_mfma_f32_16x16x4f32(opA[(j + PAR) & 1][pq * 2 + ks], opB[(j + PAR) & 1][pq][blk * 2 + ks], acc[pp][blk], 0, 0, 0);
+                    WN_FENCE();
+                }
+                if constexpr (more1 && j == 0 && i == 1) dma_u(std::integral_constant<int, 0>{}, nxt);
+                if constexpr (more1 && j == 0 && i == 5) dma_u(std::integral_constant<int, 1>{}, nxt);
+                if constexpr (more1 && j == 1 && i == 1) dma_u(std::integral_constant<int, 2>{}, nxt);
+                if constexpr (more2 && j == 1 && i == 5) dma_x(cur);
+                if constexpr (more1 && j == 1 && (i == 2 || i == 3 || i == 6)) t_load(std::integral_constant<int, i == 6 ? 2 : i - 2>{}, xaddr);
+                if constexpr (more1 && j == 2 && i == 1) t_cols();
+                if constexpr (more1 && j == 2 && i == 3) t_rows();
+                if constexpr (more1 && j == 3 && (i & 1)) t_store(std::integral_constant<int, (i >> 1)>{}, vaddr);
+                if constexpr (more1 && j == 3 && i == 6) t_store(std::integral_constant<int, 4>{}, vaddr);
+                WN_FENCE();
+            });
+        });
+        if constexpr (more2) x_advance();
+        if constexpr (more1) u_advance();
+        if (++c_chunk == S) {
+            tile_epilogue(c_cotile, c_n, c_oy0, c_ox0, c_par);
+            c_chunk = 0; c_b += J; c_par ^= 1;
+            if (c_b < xe) {
+                decode(c_b, c_cotile, c_n, c_oy0, c_ox0);
+                stage_bias(c_b, c_par);
+            }
+        }
+        WN_FENCE();
+    };
+    {
+        using P0 = std::integral_constant<int, 0>;
+        using P1 = std::integral_constant<int, 1>;
+        int g = 0;
+        for (; g + 2 < total; ++g) { if (g & 1) run_stage(std::true_type{}, std::true_type{}, P1{}, g); else run_stage(std::true_type{}, std::true_type{}, P0{}, g); }
+        if (g + 1 < total) { if (g & 1) run_stage(std::true_type{}, std::false_type{}, P1{}, g); else run_stage(std::true_type{}, std::false_type{}, P0{}, g); ++g; }
+        if (g & 1) run_stage(std::false_type{}, std::false_type{}, P1{}, g); else run_stage(std::false_type{}, std::false_type{}, P0{}, g);
+    }
+#undef WN_FENCE
+#undef WN_WAIT_LDS
+}
+
+extern "C" size_t dcvic_wino_ups_packed_bytes(int Cin, int Cout) {
+    if (Cin <= 0 || Cout <= 0) return 0;
+    return (size_t)((Cout + WN_CO - 1) / WN_CO) * ((Cin + KC - 1) / KC) * WU_US * sizeof(float);
+}
+
+extern "C" int dcvic_wino_ups_pack_f32(const float* w, float* packed, int Cin, int Cout, void* stream) {
+    DCVIC_CHECK_ARG(w && packed && Cin > 0 && Cout > 0, "wino_ups_pack: bad argument");
+    const int n_chunks = (Cin + KC - 1) / KC;
+    const long long total = (long long)((Cout + WN_CO - 1) / WN_CO) * n_chunks * WU_US;
+    wino_ups_pack_kernel<<<dcvic_cdiv(total, 256), 256, 0, (hipStream_t)stream>>>(w, packed, Cin, Cout, n_chunks, total);
+    DCVIC_CHECK_LAUNCH("wino_ups_pack");
+    return DCVIC_OK;
+}
+
+extern "C" int dcvic_conv3x3_wino_ups_f32(int Cin, int Cout, const float* packed, const dcvic_conv_io* io, void* stream) {
+    DCVIC_CHECK_ARG(packed && io && io->out && Cin > 0 && Cout > 0, "conv3x3_wino_ups: null pointer");
+    DCVIC_CHECK_ARG(io->n_src >= 1 && io->n_src <= DCVIC_MAX_SRC, "conv3x3_wino_ups: n_src %d", io->n_src);
+    int csum = 0;
+    for (int i = 0; i < io->n_src; ++i) {
+        DCVIC_CHECK_ARG(io->src[i].ptr && io->src[i].C > 0 && io->src[i].C % KC == 0, "conv3x3_wino_ups: source %d needs a multiple of 8 channels", i);
+        DCVIC_CHECK_ARG(io->src[i].batch_stride >= (long long)io->src[i].C * io->H * io->W, "conv3x3_wino_ups: source %d batch stride too small", i);
+        DCVIC_CHECK_ARG((reinterpret_cast<uintptr_t>(io->src[i].ptr) & 15) == 0 && (io->src[i].batch_stride & 3) == 0,
+                        "conv3x3_wino_ups: source %d must be 16-byte aligned", i);
+        csum += io->src[i].C;
+    }
+    DCVIC_CHECK_ARG(csum == Cin, "conv3x3_wino_ups: sources carry %d channels, layer expects %d", csum, Cin);
+    DCVIC_CHECK_ARG(io->N > 0 && io->H > 0 && io->W > 0 && (io->W & 3) == 0, "conv3x3_wino_ups: bad sizes (input width must be a multiple of 4)");
+    DCVIC_CHECK_ARG(io->Hfull == 2 * io->H && io->Wfull == 2 * io->W && io->Hout == io->Hfull && io->Wout == io->Wfull && io->osy == 1 && io->osx == 1 &&
+                    io->ooy == 0 && io->oox == 0, "conv3x3_wino_ups: output must be the x2 plane");
+    DCVIC_CHECK_ARG(!io->aff_scale && !io->aff_shift && !io->init, "conv3x3_wino_ups: affine / init epilogues are not supported");
+    DCVIC_CHECK_ARG((long long)io->H * io->W * KC < (1ll << 31), "conv3x3_wino_ups: plane too large");
+    const long long HWo = (long long)io->Hfull * io->Wfull;
+    DCVIC_CHECK_ARG(io->out_batch_stride >= (long long)Cout * HWo && (io->out_batch_stride & 3) == 0 &&
+                    (reinterpret_cast<uintptr_t>(io->out) & 15) == 0, "conv3x3_wino_ups: output view must be 16-byte aligned");
+    DCVIC_CHECK_ARG(!io->res || (io->res_batch_stride >= (long long)Cout * HWo && (io->res_batch_stride & 3) == 0 &&
+                                 (reinterpret_cast<uintptr_t>(io->res) & 15) == 0), "conv3x3_wino_ups: residual view must be 16-byte aligned");
+    ConvKArgs K;
+    memset(&K, 0, sizeof(K));
+    K.Cin = Cin; K.Cout = Cout; K.T = 9; K.stride = 1;
+    K.N = io->N; K.H = io->H; K.W = io->W; K.Hout = io->Hfull; K.Wout = io->Wfull; K.Hfull = io->Hfull; K.Wfull = io->Wfull;
+    K.osy = K.osx = 1;
+    for (int i = 0; i < DCVIC_MAX_SRC; ++i) {
+        if (i < io->n_src) { K.src[i] = io->src[i].ptr; K.srcC[i] = io->src[i].C; K.src_bs[i] = io->src[i].batch_stride; }
+        else { K.src[i] = io->src[0].ptr; K.srcC[i] = 1 << 30; K.src_bs[i] = 0; }
+    }
+    K.out = io->out; K.out_bs = io->out_batch_stride; K.bias = io->bias; K.act = io->act;
+    K.res = io->res; K.res_bs = io->res_batch_stride;
+    K.wp = packed;
+    K.n_chunks = (Cin + KC - 1) / KC;
+    K.n_cotiles = (Cout + WN_CO - 1) / WN_CO;
+    K.tiles_y = (io->Hfull + WN_TH - 1) / WN_TH;
+    K.tiles_x = (io->Wfull + WN_TW - 1) / WN_TW;
+    const long long blocks = (long long)io->N * K.tiles_y * K.tiles_x * K.n_cotiles;
+    DCVIC_CHECK_ARG(blocks < (1ll << 31), "conv3x3_wino_ups: grid too large");
+    K.nblocks = (int)blocks;
+    static std::atomic<unsigned> attr_mask{0};
+    if (dcvic_first_use_on_device(attr_mask))
+        hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_wino_ups_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    int grid = (dcvic_num_cu() / NXCD) * NXCD;
+    if (grid < NXCD) grid = NXCD;
+    if ((long long)grid > blocks) grid = (int)((blocks + NXCD - 1) / NXCD) * NXCD;
+    conv3x3_wino_ups_kernel<<<grid, WN_THREADS, WN_LDS_FLOATS * sizeof(float), (hipStream_t)stream>>>(K);
+    DCVIC_CHECK_LAUNCH("conv3x3_wino_ups");
+    return DCVIC_OK;
 }
 
 extern "C" size_t dcvic_wino_packed_bytes(int Cin, int Cout) {

@@ -81,7 +81,7 @@ def allow_winograd(module: nn.Module, on: bool = True) -> nn.Module:
     decoder and the SFT fusion blocks -- the layers after the path's last integer decision (the estimator argmax); the
     encoder side, hyperprior, CHARM, the ELIC decoder taps and the estimator keep the layer-defined reduction order."""
     for m in module.modules():
-        if isinstance(m, Conv2d) and m.kernel_size == 3 and m.stride == 1 and m.padding == 1 and not m.asym_pad and not m.upsample:
+        if isinstance(m, Conv2d) and m.kernel_size == 3 and m.stride == 1 and m.padding == 1 and not m.asym_pad:   # (incl. the Upsample convs)
             m.wino = on
     return module
 

@@ -66,6 +66,8 @@ def conv_kernel_name(variant: int) -> str:
         return "void conv3x3_dma_kernel<3, 3, 4, 96>(ConvKArgs)"
     if variant == 9100:
         return "void conv3x3_wino_kernel<0>(ConvKArgs)"
+    if variant == 9101:
+        return "conv3x3_wino_ups_kernel(ConvKArgs)"
     if 7000 <= variant < 8000:                       # conv1x1.hip: 7000 + cls
         return f"void conv1x1_dma_kernel<{(128, 64, 32, 96)[variant - 7000]}>(ConvKArgs)"
     if 8500 <= variant < 9000:                       # conv_async16.hip: 8500 + cls*100 + P/32 (tiles in units of 16)
@@ -133,6 +135,7 @@ class ConvPlan:
 
     wino = False          # set by the owner: Winograd F(2x2,3x3) allowed (no integer decision downstream of this layer)
     _wino_pack = None
+    _wino_ups_pack = None
 
     def __init__(self, weight: Tensor, bias: Optional[Tensor], kind: str = "conv", stride: int = 1,
                  pad: Tuple[int, int] = (0, 0), upsample: bool = False):
@@ -215,10 +218,19 @@ class ConvPlan:
         if self.kind != "conv" or self.upsample or self.ups_phases or self.stride != 1 or self.pad != (1, 1) \
                 or (self.KH, self.KW) != (3, 3) or self._w is None:
             return False
-        if (W & 3) or self.Cout < 48 or any(s.shape[1] % 8 or s.data_ptr() % 16 or (s.shape[0] > 1 and s.stride(0) % 4) for s in srcs):
+        if (W & 3) or (8 < self.Cout < 48) or any(s.shape[1] % 8 or s.data_ptr() % 16 or (s.shape[0] > 1 and s.stride(0) % 4) for s in srcs):
             return False
         ty, tx = (H + 7) // 8, (W + 31) // 32
         if H * W < 0.6 * (ty * 8 * tx * 32):
+            return False
+        return ty * tx * ((self.Cout + 63) // 64) >= WINO_MIN_BLOCKS
+
+    def _wino_ups_ok(self, srcs, H: int, W: int) -> bool:
+        """Eligibility of the upsample-fused Winograd (input H x W, output 2H x 2W): as _wino_ok, on the output's tile grid."""
+        if (W & 3) or self.Cout < 48 or any(s.shape[1] % 8 or s.data_ptr() % 16 or (s.shape[0] > 1 and s.stride(0) % 4) for s in srcs):
+            return False
+        ty, tx = (2 * H + 7) // 8, (2 * W + 31) // 32
+        if 4 * H * W < 0.6 * (ty * 8 * tx * 32):
             return False
         return ty * tx * ((self.Cout + 63) // 64) >= WINO_MIN_BLOCKS
 
@@ -289,7 +301,8 @@ class ConvPlan:
             if sc.shape[0] not in (1, N):
                 raise ValueError("conv affine batch must be 1 or N")
         st = _stream()
-        if self.wino and WINO_ENABLED and init is None and affine is None and (self.wino == "force" or self._wino_ok(srcs, N, H, W)) \
+        if self.wino and WINO_ENABLED and not self.ups_phases and not self.upsample and init is None and affine is None \
+                and (self.wino == "force" or self._wino_ok(srcs, N, H, W)) \
                 and out.data_ptr() % 16 == 0 and _bs(out) % 4 == 0 and (res is None or (res.data_ptr() % 16 == 0 and _bs(res) % 4 == 0)):
             if self._wino_pack is None:
                 nbytes = lib().dcvic_wino_packed_bytes(self.Cin, self.Cout)
@@ -306,6 +319,26 @@ class ConvPlan:
                 _EVENTS.append((9100, 2.0 * N * H * W * self.Cout * self.Cin * 9, e0, e1, (self.Cin, self.Cout, 9, 1, 0, H, W, N)))
             else:
                 check(lib().dcvic_conv3x3_wino_f32(self.Cin, self.Cout, _p(self._wino_pack), C.byref(io), st), "conv3x3_wino")
+            return out
+        if self.wino and WINO_ENABLED and self.ups_phases and self._w is not None and init is None and affine is None \
+                and (self.wino == "force" or self._wino_ups_ok(srcs, H, W)) \
+                and out.data_ptr() % 16 == 0 and _bs(out) % 4 == 0 and (res is None or (res.data_ptr() % 16 == 0 and _bs(res) % 4 == 0)):
+            # nearest x2 + conv3x3 as the 9-position structured Winograd (csrc/wino.hip) instead of four 2x2 phase convolutions
+            if self._wino_ups_pack is None:
+                nbytes = lib().dcvic_wino_ups_packed_bytes(self.Cin, self.Cout)
+                self._wino_ups_pack = torch.empty(nbytes // 4, dtype=torch.float32, device=self._w.device)
+                check(lib().dcvic_wino_ups_pack_f32(_p(self._w), _p(self._wino_ups_pack), self.Cin, self.Cout, st), "wino_ups_pack")
+            io.Hout, io.Wout = Hf, Wf
+            io.osy = io.osx = 1
+            io.ooy = io.oox = 0
+            if _EVENTS is not None:
+                e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+                e0.record()
+                check(lib().dcvic_conv3x3_wino_ups_f32(self.Cin, self.Cout, _p(self._wino_ups_pack), C.byref(io), st), "conv3x3_wino_ups")
+                e1.record()
+                _EVENTS.append((9101, 2.0 * N * Hf * Wf * self.Cout * self.Cin * 9, e0, e1, (self.Cin, self.Cout, 9, 1, 1, H, W, N)))
+            else:
+                check(lib().dcvic_conv3x3_wino_ups_f32(self.Cin, self.Cout, _p(self._wino_ups_pack), C.byref(io), st), "conv3x3_wino_ups")
             return out
         for phi, ph in enumerate(self.phases):
             d, packs, py, px = ph

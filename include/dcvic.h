@@ -149,6 +149,13 @@ int dcvic_conv2d_f32(const dcvic_conv_desc* d, const float* packed, const dcvic_
 size_t dcvic_wino_packed_bytes(int Cin, int Cout);
 int dcvic_wino_pack_f32(const float* w, float* packed, int Cin, int Cout, void* stream);
 int dcvic_conv3x3_wino_f32(int Cin, int Cout, const float* packed, const dcvic_conv_io* io, void* stream);
+/* Nearest-x2 upsample + Conv2d(k3, s1, p1) (ldm Upsample, model.py:42-57) as a structured Winograd: an output tile aligned to
+ * the 2x2 upsample blocks sees input rows [a, b, b, c], whose transform has a zero third row / column -- 9 of the 16 positions,
+ * 2.25 multiplies per output (the four 2x2 sub-pixel phases of dcvic_conv2d_f32 execute 4).  io: H x W = the LOW-resolution
+ * input, Hout = Hfull = 2H, Wout = Wfull = 2W, W % 4 == 0; otherwise the contract of dcvic_conv3x3_wino_f32. */
+size_t dcvic_wino_ups_packed_bytes(int Cin, int Cout);
+int dcvic_wino_ups_pack_f32(const float* w, float* packed, int Cin, int Cout, void* stream);
+int dcvic_conv3x3_wino_ups_f32(int Cin, int Cout, const float* packed, const dcvic_conv_io* io, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Batched strided GEMM  C[b][m][n] = alpha * sum_k A[b][m][k] * B[b][k][n]

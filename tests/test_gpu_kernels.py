@@ -743,3 +743,27 @@ def test_wino_eligibility_is_a_function_of_layer_and_image_only(dev):
     assert not plan._wino_ok([torch.empty((1, 124, 64, 64), device=dev), torch.empty((1, 4, 64, 64), device=dev)], 1, 64, 64)
     y_auto = plan(torch.zeros((1, 128, 8, 8), device=dev))            # falls back to the direct kernel
     assert y_auto.shape == (1, 128, 8, 8)
+
+
+@pytest.mark.parametrize("case", [(8, 64, 4, 16, 1), (16, 64, 6, 12, 2), (64, 128, 17, 36, 2), (256, 192, 32, 32, 2), (24, 64, 64, 64, 3)])
+def test_wino_upsample_conv(dev, case):
+    """dcvic_conv3x3_wino_ups_f32 (nearest x2 + conv3x3 as the 9-position structured Winograd) vs torch in fp64: same
+    tolerance as test_wino_conv3x3; odd stage counts exercise both operand-set parities, (24, ..., 3) the persistent tile loop."""
+    from dc_vic_amd import ops
+    Cin, Cout, H, W, N = case
+    x = rnd(N, Cin, H, W, seed=41)
+    w = rnd(Cout, Cin, 3, 3, seed=42, scale=(Cin * 9) ** -0.5)
+    b = rnd(Cout, seed=43, scale=0.1)
+    ref = F.conv2d(F.interpolate(x.double(), scale_factor=2, mode="nearest"), w.double(), b.double(), padding=1)
+    phases = ops.ConvPlan(w.to(dev), b.to(dev), "conv", pad=(1, 1), upsample=True)
+    wino = ops.ConvPlan(w.to(dev), b.to(dev), "conv", pad=(1, 1), upsample=True)
+    wino.wino = "force"
+    yp = phases(x.to(dev))
+    yw = wino(x.to(dev))
+    assert yw.shape == ref.shape
+    sc = float(ref.abs().max())
+    ep = float((yp.double().cpu() - ref).abs().max()) / sc
+    ew = float((yw.double().cpu() - ref).abs().max()) / sc
+    assert ew < 2e-6, (ew, ep)
+    y1 = wino(x[:1].contiguous().to(dev))
+    assert torch.equal(y1, yw[:1])            # batch-invariant

@@ -48,11 +48,50 @@ def run(Cin, Cout, H, W, N, reps=5, res=False, act=0, check=True, srcs_split=Non
     print(msg, flush=True)
 
 
+def run_ups(Cin, Cout, H, W, N, reps=5, check=True):
+    """nearest x2 + conv3x3: structured Winograd against the four 2x2 phase convolutions (and fp64 torch)."""
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(Cin * 3 + Cout + H)
+    x = torch.randn((N, Cin, H, W), generator=g).to(dev)
+    w = (torch.randn((Cout, Cin, 3, 3), generator=g) * (Cin * 9) ** -0.5).to(dev)
+    b = torch.randn(Cout, generator=g).to(dev)
+    direct = ops.ConvPlan(w, b, "conv", pad=(1, 1), upsample=True)
+    wino = ops.ConvPlan(w, b, "conv", pad=(1, 1), upsample=True); wino.wino = "force"
+    yd = direct(x); yw = wino(x)
+    torch.cuda.synchronize()
+    msg = f"ups {Cin}->{Cout} {H}x{W}->x2 N={N}:"
+    if check:
+        ref = F.conv2d(F.interpolate(x.double().cpu(), scale_factor=2, mode="nearest"), w.double().cpu(), b.double().cpu(), padding=1)
+        sc = ref.abs().max().item()
+        ed = (yd.double().cpu() - ref).abs().max().item() / sc
+        ew = (yw.double().cpu() - ref).abs().max().item() / sc
+        msg += f" err phases {ed:.2e} wino {ew:.2e}"
+        assert ew < 2e-5, msg
+    for name, plan in (("phases", direct), ("wino", wino)):
+        out = torch.empty_like(yd)
+        plan(x, out=out); torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            plan(x, out=out)
+        e1.record(); torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / reps
+        msg += f" | {name} {ms:.3f} ms"
+    print(msg, flush=True)
+
+
 if __name__ == "__main__":
     mode = sys.argv[1] if len(sys.argv) > 1 else "all"
     if mode == "one":       # one Cin Cout H W N [res] [reps]: a single shape, Winograd only (for rocprofv3 --pmc)
         a = [int(v) for v in sys.argv[2:]]
         run(a[0], a[1], a[2], a[3], a[4], reps=a[6] if len(a) > 6 else 5, res=bool(a[5]) if len(a) > 5 else False, check=False)
+    if mode in ("all", "ups"):
+        run_ups(8, 64, 4, 16, 1)
+        run_ups(16, 64, 6, 12, 2)
+        run_ups(64, 128, 17, 36, 2)
+        run_ups(256, 256, 128, 128, 32, check=False)
+        run_ups(256, 256, 64, 64, 32, check=False)
+        run_ups(512, 512, 32, 32, 32, check=False)
     if mode in ("all", "check"):
         run(8, 64, 8, 32, 1)
         run(16, 64, 10, 28, 2)
