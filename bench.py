@@ -225,7 +225,7 @@ def main():
             # issues only 16/36 of those multiplies on the matrix pipe, so its `frac` exceeds 1.0; `executed_tflops` /
             # `executed_frac` price the MFMA flops it actually executes (a true pipe utilisation <= 1).
             def executed_factor(name):
-                return 16.0 / 36.0 if "wino" in name else 1.0
+                return 9.0 / 36.0 if "wino_ups" in name else (16.0 / 36.0 if "wino" in name else 1.0)   # structured (upsample) / plain Winograd
             alg = k["flops"] / k["time_s"] / 1e12
             exe = alg * executed_factor(k["kernel"])
             out["roofline"] = {"bound": "mfma", "kernel": k["kernel"], "achieved": alg,
