@@ -47,32 +47,13 @@ __global__ __launch_bounds__(512) void groupnorm_kernel(const float* __restrict_
     // one statistics pass: sum and sum of squares accumulated in fp64 (E[x^2] - mean^2 is then exact to fp32
     // accuracy, no second read of the group), reduced in a fixed order
     double s = 0.0, q = 0.0;
-    const unsigned T = blockDim.x;
     if (vec) {
-        // four independent 16-byte loads in flight per thread (32 KiB per workgroup): one load per iteration left the kernel
-        // latency-bound at 2.6 TB/s on the 1 MiB groups of the 256^2 maps.  32-bit indices: len / 4 < 2^31 for every map the
-        // conv kernels accept.
         const float4* x4 = reinterpret_cast<const float4*>(xp);
-        const unsigned len4 = (unsigned)(len / 4);
-        unsigned i = threadIdx.x;
-        double s1 = 0.0, q1 = 0.0;
-        for (; i + 3 * T < len4; i += 4 * T) {
-            const float4 a = x4[i], b = x4[i + T], c = x4[i + 2 * T], d = x4[i + 3 * T];
-            s += ((double)a.x + (double)a.y) + ((double)a.z + (double)a.w);
-            q += ((double)a.x * a.x + (double)a.y * a.y) + ((double)a.z * a.z + (double)a.w * a.w);
-            s1 += ((double)b.x + (double)b.y) + ((double)b.z + (double)b.w);
-            q1 += ((double)b.x * b.x + (double)b.y * b.y) + ((double)b.z * b.z + (double)b.w * b.w);
-            s += ((double)c.x + (double)c.y) + ((double)c.z + (double)c.w);
-            q += ((double)c.x * c.x + (double)c.y * c.y) + ((double)c.z * c.z + (double)c.w * c.w);
-            s1 += ((double)d.x + (double)d.y) + ((double)d.z + (double)d.w);
-            q1 += ((double)d.x * d.x + (double)d.y * d.y) + ((double)d.z * d.z + (double)d.w * d.w);
-        }
-        for (; i < len4; i += T) {
+        for (long long i = threadIdx.x; i < len / 4; i += blockDim.x) {
             const float4 v = x4[i];
             s += ((double)v.x + (double)v.y) + ((double)v.z + (double)v.w);
             q += ((double)v.x * v.x + (double)v.y * v.y) + ((double)v.z * v.z + (double)v.w * v.w);
         }
-        s += s1; q += q1;
     } else {
         for (long long i = threadIdx.x; i < len; i += blockDim.x) { const double v = xp[i]; s += v; q += v * v; }
     }
@@ -84,32 +65,16 @@ __global__ __launch_bounds__(512) void groupnorm_kernel(const float* __restrict_
     if (vec) {
         const float4* x4 = reinterpret_cast<const float4*>(xp);
         float4* y4 = reinterpret_cast<float4*>(yp);
-        const unsigned hw4 = (unsigned)(HW / 4);
-        auto apply = [&](float4 v, float ga, float be) {          // (x - mean) * rstd * gamma + beta, in the reference's order
-            v.x = dcvic_act((v.x - mean) * rstd * ga + be, act); v.y = dcvic_act((v.y - mean) * rstd * ga + be, act);
-            v.z = dcvic_act((v.z - mean) * rstd * ga + be, act); v.w = dcvic_act((v.w - mean) * rstd * ga + be, act);
-            return v;
-        };
-        if (hw4 >= 4 * T) {
-            // big planes: channel by channel (gamma / beta are scalars of the loop, no index division), four loads in flight
-            for (int cc = 0; cc < cg; ++cc) {
-                const float ga = gamma[g * cg + cc], be = beta[g * cg + cc];
-                const float4* xc = x4 + (size_t)cc * hw4;
-                float4* yc = y4 + (size_t)cc * hw4;
-                unsigned i = threadIdx.x;
-                for (; i + 3 * T < hw4; i += 4 * T) {
-                    const float4 a = xc[i], b = xc[i + T], c = xc[i + 2 * T], d = xc[i + 3 * T];
-                    yc[i] = apply(a, ga, be); yc[i + T] = apply(b, ga, be); yc[i + 2 * T] = apply(c, ga, be); yc[i + 3 * T] = apply(d, ga, be);
-                }
-                for (; i < hw4; i += T) yc[i] = apply(xc[i], ga, be);
-            }
-        } else {
-            const unsigned len4 = (unsigned)(len / 4);
-            for (unsigned i = threadIdx.x; i < len4; i += T) {
-                const int c = g * cg + (int)(i / hw4);
-                const float ga = gamma[c], be = beta[c];
-                y4[i] = apply(x4[i], ga, be);
-            }
+        const int hw4 = HW / 4;
+        for (long long i = threadIdx.x; i < len / 4; i += blockDim.x) {
+            const int c = g * cg + (int)(i / hw4);
+            const float ga = gamma[c], be = beta[c];
+            float4 v = x4[i];
+            v.x = dcvic_act((v.x - mean) * rstd * ga + be, act);
+            v.y = dcvic_act((v.y - mean) * rstd * ga + be, act);
+            v.z = dcvic_act((v.z - mean) * rstd * ga + be, act);
+            v.w = dcvic_act((v.w - mean) * rstd * ga + be, act);
+            y4[i] = v;
         }
     } else {
         for (long long i = threadIdx.x; i < len; i += blockDim.x) {

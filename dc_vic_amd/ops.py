@@ -218,7 +218,7 @@ class ConvPlan:
         if self.kind != "conv" or self.upsample or self.ups_phases or self.stride != 1 or self.pad != (1, 1) \
                 or (self.KH, self.KW) != (3, 3) or self._w is None:
             return False
-        if (W & 3) or (8 < self.Cout < 48) or any(s.shape[1] % 8 or s.data_ptr() % 16 or (s.shape[0] > 1 and s.stride(0) % 4) for s in srcs):
+        if (W & 3) or self.Cout < 48 or any(s.shape[1] % 8 or s.data_ptr() % 16 or (s.shape[0] > 1 and s.stride(0) % 4) for s in srcs):
             return False
         ty, tx = (H + 7) // 8, (W + 31) // 32
         if H * W < 0.6 * (ty * 8 * tx * 32):
