@@ -1,29 +1,34 @@
 // wino.hip -- 3x3 / stride-1 / pad-1 convolution as Winograd F(2x2, 3x3) on fp32 MFMA, gfx950.
 //
-// Replaces the same torch.nn.Conv2d(k3, s1, p1) layers as conv3x3.hip, but ONLY where no integer decision depends on the
-// result bit for bit: the frozen VQGAN decoder + SFT fusion after the estimator's argmax (ldm/modules/diffusionmodules/
-// model.py:82-141, 462-568; src/models/layer/codeformer_layers.py:20-67; src/models/subnet/vq_fusion_module.py:78-126).
-// Everything that feeds the VQ argmin, the rANS symbols / cdf indexes or the estimator argmax stays on the direct kernels,
-// whose reduction order is the layer-defined fmaf chain.  Winograd re-associates: Y = A^T [ sum_ci (G g G^T) . (B^T d B) ] A
-// executes 16 multiplies per 2x2 outputs and input channel instead of 36 (4/9 of the MFMA work) and differs from the
-// direct sum at the 1e-6 relative level (tolerances in tests/test_gpu_kernels.py::test_wino_*).
+// Replaces the same torch.nn.Conv2d(k3, s1, p1) layers as conv3x3.hip, but only where the caller opted in
+// (dc_vic_amd.layers.allow_winograd): the frozen VQGAN decoder + SFT fusion after the estimator's argmax and the VQGAN encoder
+// (ldm/modules/diffusionmodules/model.py:82-141, 368-568; src/models/layer/codeformer_layers.py:20-67;
+// src/models/subnet/vq_fusion_module.py:78-126).  Hyper-decoder and CHARM (whose results encoder and decoder must reproduce
+// bit for bit), both ELIC networks and the estimator stay on the direct kernels' layer-defined fmaf order.  Winograd
+// re-associates: Y = A^T [ sum_ci (G g G^T) . (B^T d B) ] A executes 16 multiplies per 2x2 outputs and input channel instead of
+// 36 (4/9 of the MFMA work) and differs from the direct sum at the 1e-6 relative level (it is closer to an fp64 convolution:
+// tests/test_gpu_kernels.py::test_wino_*).  Further down: conv3x3_wino_ups_kernel, the 9-position structured form for
+// nearest-x2 upsample + conv3x3.
 //
-// One workgroup = 512 threads = 8 waves (2 per SIMD) on 64 output channels x (8 rows x 32 columns) = 64 tiles of 2x2.
+// One PERSISTENT workgroup per CU = 512 threads = 8 waves (2 per SIMD); a tile is 64 output channels x (8 rows x 32 columns)
+// = 64 tiles of 2x2, all stages of all its tiles one continuous stream.
 //   * a pipeline stage is 8 input channels.  Per stage the raw input patch (8 ch x 10 rows x ten 16-byte segments, zero
-//     padded through a zero source) and the pre-transformed weights U (16 positions x 8 ch x 64 co = 32 KiB, packed by wino_pack_kernel in the
-//     exact LDS image) arrive by LDS-DMA (`global_load_lds_dword / _dwordx4`), two stages / one stage ahead;
-//   * every thread transforms ONE (channel, tile) 4x4 patch per stage (8 ds_read_b64, 32 adds, 16 ds_write_b32) into the
-//     V image of the NEXT stage while the MFMAs of the current stage run;
+//     padded through a zero source) and the pre-transformed weights U (16 positions x 8 ch x 64 co = 32 KiB, packed by
+//     wino_pack_kernel in the exact LDS image) arrive by LDS-DMA (`global_load_lds_dwordx4`), two stages / one stage ahead;
+//   * every thread transforms ONE (channel, tile) 4x4 patch per stage (8 ds_read2_b32, 32 adds, 8 ds_write2st64_b32) into the
+//     V image of the NEXT stage, its instructions placed behind the MFMAs of the current stage;
 //   * wave w = (co group cg = w % 4 of 16 channels, tile half th = w / 4 of 32 tiles) owns ALL 16 Winograd positions of its
 //     16 x 32 block: per position two `v_mfma_f32_16x16x4_f32` accumulators (128 accumulator registers per lane), fed by
 //     ONE ds_read_b128 per position pair (U: two positions x both k-steps) and ONE ds_read_b128 per position (V: two
 //     16-tile blocks x both k-steps) -- U pair-slab word ((cg*4 + k)*16 + m)*4 + pq*2 + ks, V slab word
 //     ((th*4 + k)*16 + n)*4 + blk*2 + ks hold channel 4ks + k;
 //   * since a lane then holds the same (co, tile) element of all 16 positions, the output transform A^T M A runs in
-//     registers: no LDS exchange and no barrier after the last stage; bias -> act -> (+res) -> float2 stores.
-// LDS: 2 x 12 KiB raw patch + 2 x 32 KiB U + 2 x 32 KiB V + bias row = 152.25 KiB: one workgroup per CU.
+//     registers: no LDS exchange and no barrier after the last stage; bias -> act -> (+res) -> 16-byte stores (DPP row swap
+//     between horizontally adjacent tiles).
+// LDS: 2 x 13 KiB raw patch + 2 x 32 KiB U + 2 x 32 KiB V + two bias rows = 154.5 KiB: one workgroup per CU.
 // Deterministic and batch-invariant: per position the reduction runs over chunks ascending, then k-steps ascending inside
-// the MFMA's ordered fmaf chain; the tiling never depends on N.
+// the MFMA's ordered fmaf chain; the tiling never depends on N.  Build log, measurements and the timing experiments behind the
+// DBG / RS template paths: profiles/r2_wino_experiments.md.
 #include "conv_common.h"
 
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
