@@ -767,3 +767,38 @@ def test_wino_upsample_conv(dev, case):
     assert ew < 2e-6, (ew, ep)
     y1 = wino(x[:1].contiguous().to(dev))
     assert torch.equal(y1, yw[:1])            # batch-invariant
+
+
+def test_wino_fuzz_vs_direct(dev):
+    """40 random layer geometries (channels, ragged sizes, 1-3 sources, residual, activation, batch) through both Winograd
+    kernels against the direct kernels: 5e-6 of the output's max (two fp32 evaluations of the same sum; each is within 2e-6 of
+    fp64 in test_wino_conv3x3).  Exercises the persistent tile loop (more tiles than workgroups), partial tiles in both
+    directions, channel tiles beyond Cout and source switches inside a tile's stage stream."""
+    from dc_vic_amd import ops
+    rng = np.random.RandomState(7)
+    for it in range(40):
+        ups = it % 4 == 3
+        n_src = int(rng.randint(1, 4))
+        cs = [8 * int(rng.randint(1, 9)) for _ in range(n_src)]
+        Cin = sum(cs)
+        Cout = int(rng.choice([48, 64, 96, 128, 192, 200, 256]))
+        H = int(rng.randint(3, 41))
+        W = 4 * int(rng.randint(1, 25))
+        N = int(rng.randint(1, 6))
+        act = int(rng.choice([0, 1, 2, 3]))
+        res = bool(rng.randint(0, 2)) and not ups
+        x = rnd(N, Cin, H, W, seed=100 + it)
+        w = rnd(Cout, Cin, 3, 3, seed=200 + it, scale=(Cin * 9) ** -0.5)
+        b = rnd(Cout, seed=300 + it, scale=0.1)
+        Ho, Wo = (2 * H, 2 * W) if ups else (H, W)
+        r = rnd(N, Cout, Ho, Wo, seed=400 + it).to(dev) if res else None
+        direct = ops.ConvPlan(w.to(dev), b.to(dev), "conv", pad=(1, 1), upsample=ups)
+        wino = ops.ConvPlan(w.to(dev), b.to(dev), "conv", pad=(1, 1), upsample=ups)
+        wino.wino = "force"
+        xs = x.to(dev)
+        srcs = [t.contiguous() for t in torch.split(xs, cs, dim=1)] if n_src > 1 else xs
+        yd = direct(srcs, act=act, res=r)
+        yw = wino(srcs, act=act, res=r)
+        sc = float(yd.abs().max())
+        err = float((yd - yw).abs().max()) / max(sc, 1e-6)
+        assert err < 5e-6, (it, ups, cs, Cout, H, W, N, act, res, err)
