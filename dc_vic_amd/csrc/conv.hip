@@ -414,6 +414,9 @@ extern "C" int dcvic_conv_select_class(const dcvic_conv_desc* d, int N, int Hout
     init_num_cu();
     int best_cls = choose_class(d->Cout);
     double best = -1.0;
+#ifdef DCVIC_CONV_EXPERIMENTS
+    if (const char* e = getenv("DCVIC_FORCE_CLS")) return atoi(e);
+#endif
     for (int cls = 0; cls < 4; ++cls)
         for (int pi = 0; pi < kClassNP[cls]; ++pi) {
             const double sc = variant_score(cls, kClassP[cls][pi], d->Cout, N, Hout, Wout, d->upsample, g_num_cu);
@@ -500,6 +503,9 @@ extern "C" int dcvic_conv2d_f32(const dcvic_conv_desc* d, const float* packed, c
             if (sc > best) { best = sc; P = kClassP[cls][pi]; }
         }
     }
+#ifdef DCVIC_CONV_EXPERIMENTS
+    if (const char* e = getenv("DCVIC_FORCE_P")) P = atoi(e);
+#endif
     DCVIC_CHECK_ARG(P > 0, "conv2d: no tile variant fits");
     const int TH = P / TW;
     K.tiles_y = (io->Hout + TH - 1) / TH;
