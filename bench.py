@@ -56,31 +56,43 @@ def cpu_baseline(sd, quality: int):
         cores = len(os.sched_getaffinity(0))      # the box's CPU share, not the host's core count
     except AttributeError:
         cores = os.cpu_count() or 1
-    cores = max(1, min(cores, int(os.environ.get("DCVIC_CPU_BASELINE_THREADS", "16"))))
+    share = cores
+    cap = int(os.environ.get("DCVIC_CPU_BASELINE_THREADS", "16"))     # torch-CPU convs stop scaling past ~16 threads on these maps
+    cores = max(1, min(cores, cap))
     torch.set_num_threads(cores)
     orc = Oracle(sd)
     g = torch.Generator().manual_seed(99)
     x = torch.rand((1, 3, 256, 256), generator=g) * 2 - 1
     r = orc.compress(x, quality)           # warm-up (first-call allocations)
     orc.decompress(r["string_list"])
-    n = 2
-    t0 = time.perf_counter()
+    n = int(os.environ.get("DCVIC_CPU_BASELINE_SAMPLES", "8"))
+    times = []
     for i in range(n):
+        t0 = time.perf_counter()
         r = orc.compress(x, quality)
         orc.decompress(r["string_list"])
-    dt = time.perf_counter() - t0
+        times.append(time.perf_counter() - t0)
+    dt = sum(times)
     return {"value": n / dt, "unit": "images/s", "cores": cores, "kind": "port",
+            "node_cores": os.cpu_count(), "process_cpu_share": share, "thread_cap": cap,
+            "best_sample_images_per_s": 1.0 / min(times), "worst_sample_images_per_s": 1.0 / max(times),
             "sample": f"{n} x (compress+decompress) of one 256x256 image, q={quality}, torch {torch.__version__} fp32 CPU oracle, "
-                      f"{cores} threads, after 1 warm-up"}
+                      f"{cores} threads (cap {cap}; this process may use {share} of the node's {os.cpu_count()} cores), after 1 warm-up"}
 
 
 def main():
     a = parse()
+    from dc_vic_amd.parallel import launched_by_a_launcher, self_launch
+    if not launched_by_a_launcher():
+        # plain `python bench.py --gpus N`: this process becomes the launcher of N ranks (one per GPU) BEFORE anything touches
+        # the GPU; fewer than N devices is an error, never a 1-rank run reported as the answer to --gpus N
+        if a.gpus > 1:
+            sys.exit(self_launch(a.gpus))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != a.gpus and world > 1:
-        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
+    if world != a.gpus:
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: the launcher's rank count and --gpus must agree")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (the path has no CPU fallback)")
     torch.cuda.set_device(local_rank)
@@ -201,9 +213,10 @@ def main():
             "per_rank_host_cores": [int(p_[2]) for p_ in per_rank],
             "stage_ms_per_step": stage_ms,
             "avg_pred_bpp": float(table[:, 1].mean() / (IH * IW)),
-            # ALGORITHMIC flop (1 009.6 GF per 256^2 image, upsample+conv counted at full 3x3 cost although the
-            # sub-pixel form executes 4/9 of it) / wall time / peak -- an end-to-end figure, not a kernel utilisation
-            "end_to_end_algorithmic_flop_frac_of_f32_mfma_peak": value / world * GFLOP_PER_IMAGE * (IH * IW) / 65536.0 / 1e3 / PEAK_F32_MFMA_TFLOPS,
+            # ALGORITHMIC work rate (1 009.6 GF per 256^2 image at direct-convolution cost) per GPU: a throughput in
+            # TFLOP/s of useful work, NOT a utilisation (Winograd skips multiplies); the utilisation is
+            # end_to_end_executed_conv_mfma_frac_of_f32_peak below
+            "end_to_end_algorithmic_tflops_per_gpu": value / world * GFLOP_PER_IMAGE * (IH * IW) / 65536.0 / 1e3,
         }
         if ev:
             k = max(ev.values(), key=lambda d: d["time_s"])
@@ -220,25 +233,25 @@ def main():
                         break
                 except (OSError, ValueError):
                     pass
-            # flop accounting: ev[*]["flops"] are ALGORITHMIC (direct-convolution 2*MAC).  `achieved` / `frac` follow the
-            # bench contract to the letter: algorithmic flops per launch / launch duration / peak.  The Winograd F(2x2,3x3) kernel
-            # issues only 16/36 of those multiplies on the matrix pipe, so its `frac` exceeds 1.0; `executed_tflops` /
-            # `executed_frac` price the MFMA flops it actually executes (a true pipe utilisation <= 1).
-            def executed_factor(name):
-                return 9.0 / 36.0 if "wino_ups" in name else (16.0 / 36.0 if "wino" in name else 1.0)   # structured (upsample) / plain Winograd
+            # flop accounting: `achieved` / `frac` are the MFMA flops the kernel EXECUTES per second (a matrix-pipe utilisation,
+            # <= 1): for a direct convolution that is the algorithmic 2*MAC count of SURVEY 8(d); Winograd F(2x2,3x3) issues 16/36
+            # of it (F(4x4,3x3) 36/144, the upsample form 9/36).  `algorithmic_tflops` keeps the direct-convolution figure, i.e.
+            # the rate at which the layer's work gets done (> peak when the algorithm skips multiplies).
             alg = k["flops"] / k["time_s"] / 1e12
-            exe = alg * executed_factor(k["kernel"])
-            out["roofline"] = {"bound": "mfma", "kernel": k["kernel"], "achieved": alg,
-                               "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": alg / PEAK_F32_MFMA_TFLOPS,
-                               "executed_tflops": exe, "executed_frac": exe / PEAK_F32_MFMA_TFLOPS,
-                               "flop_accounting": ("achieved / frac = ALGORITHMIC direct-convolution flops (SURVEY 8d: 2*N*H*W*Cout*Cin*9 per launch) per second; "
-                                                   "Winograd F(2x2,3x3) executes 16/36 of those multiplies, which is why frac > 1: executed_* are the MFMA flops "
-                                                   "actually issued (matrix-pipe utilisation)") if "wino" in k["kernel"] else "direct sum: executed = algorithmic",
+            exe = k["exec_flops"] / k["time_s"] / 1e12
+            tot_exec = sum(d["exec_flops"] for d in ev.values())
+            out["end_to_end_executed_conv_mfma_frac_of_f32_peak"] = tot_exec / dt / 1e12 / PEAK_F32_MFMA_TFLOPS
+            out["roofline"] = {"bound": "mfma", "kernel": k["kernel"], "achieved": exe,
+                               "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": exe / PEAK_F32_MFMA_TFLOPS,
+                               "algorithmic_tflops": alg, "executed_per_algorithmic_flop": k["exec_flops"] / k["flops"],
+                               "flop_accounting": "achieved / frac = MFMA flops EXECUTED per second / fp32 matrix peak (pipe utilisation); "
+                                                  "algorithmic_tflops = SURVEY 8d direct-convolution flops (2*N*H*W*Cout*Cin*9 per launch) per second",
                                "traffic": traffic, "traffic_source": traffic_src, "launches": k["launches"], "avg_launch_us": 1e6 * k["time_s"] / k["launches"],
                                "gflop_per_launch": k["flops"] / k["launches"] / 1e9,
+                               "executed_gflop_per_launch": k["exec_flops"] / k["launches"] / 1e9,
                                "share_of_step_time": k["time_s"] / dt,
-                               "all_conv_kernels": {n: {"tflops": d["flops"] / d["time_s"] / 1e12,
-                                                        "executed_tflops": d["flops"] / d["time_s"] / 1e12 * executed_factor(n), "launches": d["launches"],
+                               "all_conv_kernels": {n: {"tflops": d["exec_flops"] / d["time_s"] / 1e12,
+                                                        "algorithmic_tflops": d["flops"] / d["time_s"] / 1e12, "launches": d["launches"],
                                                         "time_share": d["time_s"] / dt} for n, d in ev.items()}}
         else:
             out["roofline"] = None

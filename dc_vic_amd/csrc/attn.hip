@@ -205,7 +205,7 @@ static int launch_attn(const AttnArgs& A, hipStream_t st) {
     static std::atomic<unsigned> attr_mask{0};
     auto k = attn_fused_kernel<C, NW>;
     const size_t lds = (size_t)2 * 64 * 80 * sizeof(float);
-    if (dcvic_first_use_on_device(attr_mask))
+    if (DcvicAttrOnce once_{attr_mask})
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     k<<<A.nblocks, NW * 64, lds, st>>>(A);
     DCVIC_CHECK_LAUNCH("attn_fused");

@@ -41,14 +41,26 @@ __device__ __forceinline__ float dcvic_act(float v, int act) {
     }
 }
 
-// Function attributes (dynamic-LDS limit) are per device: returns true the first time the calling site runs
-// on the current HIP device (bit per ordinal in a site-local mask; devices >= 32 simply re-apply every call).
-static inline bool dcvic_first_use_on_device(std::atomic<unsigned>& mask) {
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 32) return true;
-    const unsigned bit = 1u << dev;
-    return (mask.fetch_or(bit, std::memory_order_acq_rel) & bit) == 0;
-}
+// Function attributes (dynamic-LDS limit) are per device.  `if (DcvicAttrOnce once{mask}) { hipFuncSetAttribute(...); }` runs the
+// body until it has COMPLETED once on the current HIP device: the device's bit in the site-local mask is set by the destructor,
+// i.e. after the attribute calls -- a second thread arriving meanwhile applies the (idempotent) attribute itself instead of
+// launching a > 64 KiB-LDS kernel before it is in effect.  Devices >= 32 re-apply on every call.
+struct DcvicAttrOnce {
+    std::atomic<unsigned>& mask;
+    unsigned bit = 0;
+    bool need = true;
+    explicit DcvicAttrOnce(std::atomic<unsigned>& m) : mask(m) {
+        int dev = 0;
+        if (hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 32) {
+            bit = 1u << dev;
+            need = (mask.load(std::memory_order_acquire) & bit) == 0;
+        }
+    }
+    ~DcvicAttrOnce() { if (need && bit) mask.fetch_or(bit, std::memory_order_release); }
+    explicit operator bool() const { return need; }
+    DcvicAttrOnce(const DcvicAttrOnce&) = delete;
+    DcvicAttrOnce& operator=(const DcvicAttrOnce&) = delete;
+};
 // Compute units of the current HIP device (cached per ordinal).
 int dcvic_num_cu();
 

@@ -374,7 +374,7 @@ static int launch_variant(const ConvKArgs& K, bool ups, size_t lds, hipStream_t 
     static std::atomic<unsigned> attr_mask{0};
     auto k0 = conv_mfma_kernel<MT, NT, WM, WN, false>;
     auto k1 = conv_mfma_kernel<MT, NT, WM, WN, true>;
-    if (dcvic_first_use_on_device(attr_mask)) {
+    if (DcvicAttrOnce once_{attr_mask}) {
         hipFuncSetAttribute(reinterpret_cast<const void*>(k0), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         hipFuncSetAttribute(reinterpret_cast<const void*>(k1), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     }

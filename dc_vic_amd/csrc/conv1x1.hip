@@ -220,7 +220,7 @@ template <int TCv>
 static int launch_1x1(const ConvKArgs& A, hipStream_t st) {
     static std::atomic<unsigned> attr_mask{0};
     auto k = conv1x1_dma_kernel<TCv>;
-    if (dcvic_first_use_on_device(attr_mask)) {
+    if (DcvicAttrOnce once_{attr_mask}) {
         hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     }
     const size_t lds = (size_t)(2 * (Q_CH * Q_P + Q_CH * TCv) + 3 * TCv) * sizeof(float);   // + bias / scale / shift rows

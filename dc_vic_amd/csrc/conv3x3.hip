@@ -417,7 +417,7 @@ static int launch_tap_dma(const ConvKArgs& A, hipStream_t st) {
     constexpr int PLANE = (D_TH + TY - 1) * (D_TW + TX - 1);
     constexpr int XS = ((SKC * PLANE + D_THREADS - 1) / D_THREADS) * D_THREADS;
     const size_t lds = (size_t)((DCVIC_CONV_STAGGER ? 3 : 2) * (XS + TY * TX * SKC * TCV) + TCV) * sizeof(float);   // + the bias row
-    if (dcvic_first_use_on_device(attr_mask)) {
+    if (DcvicAttrOnce once_{attr_mask}) {
         hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     }
     k<<<A.nblocks, D_THREADS, lds, st>>>(A);

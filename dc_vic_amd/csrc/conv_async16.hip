@@ -317,7 +317,7 @@ static int launch_async16(const ConvKArgs& K, int xs_floats, int ws_floats, hipS
     static std::atomic<unsigned> attr_mask{0};
     auto k1 = conv_mfma_async16_kernel<M16, N16, WM, WN, false>;
     auto k2 = conv_mfma_async16_kernel<M16, N16, WM, WN, true>;
-    if (dcvic_first_use_on_device(attr_mask)) {
+    if (DcvicAttrOnce once_{attr_mask}) {
         hipFuncSetAttribute(reinterpret_cast<const void*>(k1), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         hipFuncSetAttribute(reinterpret_cast<const void*>(k2), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     }

@@ -317,11 +317,11 @@ extern "C" int dcvic_vq_argmin_f32(const float* z, const float* codebook, int64_
         }
     } else if (D == 4) {
         static std::atomic<unsigned> m4{0};
-        if (dcvic_first_use_on_device(m4)) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(vq_argmin_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (DcvicAttrOnce once_{m4}) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(vq_argmin_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         vq_argmin_kernel<4><<<grid, 256, lds, (hipStream_t)stream>>>(z, codebook, idx, zq, feat, HW, n_e);
     } else {
         static std::atomic<unsigned> m8{0};
-        if (dcvic_first_use_on_device(m8)) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(vq_argmin_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (DcvicAttrOnce once_{m8}) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(vq_argmin_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         vq_argmin_kernel<8><<<grid, 256, lds, (hipStream_t)stream>>>(z, codebook, idx, zq, feat, HW, n_e);
     }
     DCVIC_CHECK_LAUNCH("vq_argmin");

@@ -858,7 +858,7 @@ extern "C" int dcvic_conv3x3_wino_ups_f32(int Cin, int Cout, const float* packed
     DCVIC_CHECK_ARG(blocks < (1ll << 31), "conv3x3_wino_ups: grid too large");
     K.nblocks = (int)blocks;
     static std::atomic<unsigned> attr_mask{0};
-    if (dcvic_first_use_on_device(attr_mask))
+    if (DcvicAttrOnce once_{attr_mask})
         hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_wino_ups_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     int grid = (dcvic_num_cu() / NXCD) * NXCD;
     if (grid < NXCD) grid = NXCD;
@@ -932,13 +932,12 @@ extern "C" int dcvic_conv3x3_wino_f32(int Cin, int Cout, const float* packed, co
     K.TG &= 15;
     auto kern = dbg == 1 ? conv3x3_wino_kernel<1> : dbg == 2 ? conv3x3_wino_kernel<2> : dbg == 4 ? conv3x3_wino_kernel<4> : dbg == 8 ? conv3x3_wino_kernel<8> :
                 dbg == 6 ? conv3x3_wino_kernel<6> : dbg == 16 ? conv3x3_wino_kernel<16> : dbg == 32 ? conv3x3_wino_kernel<32> : dbg == 64 ? conv3x3_wino_kernel<64> : dbg == 128 ? conv3x3_wino_kernel<128> : dbg == 256 ? conv3x3_wino_kernel<256> : conv3x3_wino_kernel<0>;
-    const bool set_attr = dcvic_first_use_on_device(attr_mask) || dbg;
+    if (dbg) hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
 #else
     auto kern = conv3x3_wino_kernel<0>;
-    const bool set_attr = dcvic_first_use_on_device(attr_mask);
 #endif
-    if (set_attr)
-        hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (DcvicAttrOnce once_{attr_mask})
+        hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_wino_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     // persistent grid: one workgroup per CU (152 KiB of LDS each), a multiple of the 8 XCDs; each walks its share of the tiles
     int grid = (dcvic_num_cu() / NXCD) * NXCD;
     if (grid < NXCD) grid = NXCD;

@@ -83,23 +83,29 @@ def conv_kernel_name(variant: int) -> str:
     return f"void conv_mfma_kernel<{_VARIANT_TILES.get((cls, P), '?')}, {'true' if ups else 'false'}>(ConvKArgs)"
 
 
+# MFMA flops a kernel EXECUTES per algorithmic (direct-convolution 2*MAC) flop: Winograd F(2x2,3x3) issues 16 multiplies per 2x2
+# outputs and input channel instead of 36, the upsample-structured form 9 of 36, F(4x4,3x3) 36 per 4x4 outputs instead of 144
+EXECUTED_FRACTION = {9100: 16.0 / 36.0, 9101: 9.0 / 36.0, 9104: 36.0 / 144.0}
+
+
 def kernel_events_start() -> None:
     global _EVENTS
     _EVENTS = []
 
 
 def kernel_events_stop():
-    """-> {kernel name: {kernel, launches, flops (algorithmic 2*MAC), time_s}}; call after a device sync."""
+    """-> {kernel name: {kernel, launches, flops (algorithmic 2*MAC), exec_flops (MFMA flops issued), time_s}}; call after a device sync."""
     global _EVENTS
     ev, _EVENTS = _EVENTS, None
     out = {}
     shapes = {}
     for cfg, flops, e0, e1, shp in ev or []:
         name = conv_kernel_name(cfg)
-        d = out.setdefault(name, {"kernel": name, "launches": 0, "flops": 0.0, "time_s": 0.0})
+        d = out.setdefault(name, {"kernel": name, "launches": 0, "flops": 0.0, "exec_flops": 0.0, "time_s": 0.0})
         t = e0.elapsed_time(e1) * 1e-3
         d["launches"] += 1
         d["flops"] += flops
+        d["exec_flops"] += flops * EXECUTED_FRACTION.get(cfg, 1.0)
         d["time_s"] += t
         sd = shapes.setdefault((cfg,) + shp, [0, 0.0, 0.0])
         sd[0] += 1; sd[1] += flops; sd[2] += t

@@ -94,3 +94,64 @@ def gather_rate_table(table: np.ndarray, dist, device=None) -> np.ndarray:
     parts = [torch.zeros_like(pad) for _ in range(world)]
     dist.all_gather(parts, pad)
     return np.concatenate([p[:c].cpu().numpy() for p, c in zip(parts, counts)], axis=0)
+
+
+# ------------------------------------------------------------------------------------------- self-launch
+def _free_port() -> int:
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        return int(s.getsockname()[1])
+
+
+def launched_by_a_launcher() -> bool:
+    """True when a launcher (torch.distributed.run, or self_launch below) already set up this process as one rank."""
+    return "WORLD_SIZE" in os.environ and "RANK" in os.environ
+
+
+def self_launch(n_ranks: int, argv: Optional[Sequence[str]] = None, need_gpus: bool = True) -> int:
+    """`prog --gpus N` typed without a launcher: become the launcher.  Starts N child processes of the same command line,
+    one per GPU (RANK = LOCAL_RANK = i, WORLD_SIZE = LOCAL_WORLD_SIZE = N, MASTER_ADDR = 127.0.0.1, a free MASTER_PORT), waits
+    for them and returns the worst exit code (the caller passes it to sys.exit).  The parent never initialises the GPU
+    (`torch.cuda.device_count()` does not, on this image) -- the children are ordinary child processes, not an exec.  Too few
+    devices is an error, never a silent 1-rank run.  If one rank fails the others are terminated (exact PIDs)."""
+    import subprocess
+    import sys
+    import time
+    if n_ranks < 1:
+        raise SystemExit(f"--gpus {n_ranks}: need at least one rank")
+    if need_gpus:
+        have = torch.cuda.device_count()
+        if have < n_ranks:
+            raise SystemExit(f"--gpus {n_ranks} requested but this node exposes {have} HIP device(s): refusing to run fewer ranks "
+                             "than asked (the path has no CPU fallback)")
+    argv = list(sys.argv if argv is None else argv)
+    port = _free_port()
+    procs = []
+    for r in range(n_ranks):
+        env = dict(os.environ)
+        env.update(RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n_ranks), LOCAL_WORLD_SIZE=str(n_ranks),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), DCVIC_SELF_LAUNCHED="1")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable] + argv, env=env))
+    rc = 0
+    try:
+        alive = list(procs)
+        while alive:
+            for p_ in list(alive):
+                c = p_.poll()
+                if c is None:
+                    continue
+                alive.remove(p_)
+                if c != 0 and rc == 0:
+                    rc = c if c > 0 else 128 - c
+                    for q in alive:                     # one rank failed: the others would wait in a collective forever
+                        q.terminate()
+            if alive:
+                time.sleep(0.05)
+    except BaseException:
+        for q in procs:
+            if q.poll() is None:
+                q.kill()
+        raise
+    return rc

@@ -82,6 +82,10 @@ class ParamGroup:
                     m._plan = None
                 if hasattr(m, "_qkv_plan"):
                     m._qkv_plan = None
+                if getattr(m, "_dgrad", None) is not None:
+                    # data-gradient plan cached while this module was NOT trainable in some Ctx (the discriminator inside the
+                    # generator step): it holds a flipped / transposed COPY of the weights, stale once Adam moved them
+                    m._dgrad = None
                 if hasattr(m, "invalidate_caches"):
                     m.invalidate_caches()
 

@@ -57,6 +57,19 @@ def allreduce_mean_(flat: Tensor, dist, bucket_bytes: int = 64 << 20) -> int:
     return len(works)
 
 
+def loss_anomaly(total: float, dist, device=None) -> bool:
+    """base_trainer.py:235-245 skips a step whose total loss is non-finite or > 1e4.  With several ranks the decision must be
+    COLLECTIVE: a rank that returned early while the others entered the gradient all-reduce would leave them blocked in RCCL
+    forever (and let the Adam / scheduler step counts diverge).  One 1-element MAX all-reduce of the local flag: every rank
+    skips or none does."""
+    bad = (not math.isfinite(total)) or total > 1e4
+    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+        return bad
+    flag = torch.tensor([1.0 if bad else 0.0], dtype=torch.float32, device=device if device is not None else "cpu")
+    dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+    return bool(flag.item() > 0)
+
+
 class MultiStepLR:
     def __init__(self, base_lr: float, milestones: List[int], gamma: float):
         self.base_lr, self.milestones, self.gamma, self.last_epoch = base_lr, sorted(milestones), gamma, 0
@@ -84,7 +97,7 @@ class Adam:
 class DualBetaCondGanDistortionVqCodeTrainer:
     def __init__(self, model, discriminator, lr_g: float = 1e-4, lr_d: float = 1e-4, milestones=(300000,), gamma: float = 0.1,
                  clip_max_norm: Optional[float] = 1.0, loss_weights: Optional[Dict[str, float]] = None, sample_beta_batch: bool = True,
-                 dist=None, seed: int = 0):
+                 dist=None, seed: int = 0, d_milestones=None, d_gamma: Optional[float] = None, lpips_state: Optional[Dict[str, Tensor]] = None):
         self.model, self.D = model, discriminator
         dev = next(model.decoder.parameters()).device
         self.device = dev
@@ -92,7 +105,9 @@ class DualBetaCondGanDistortionVqCodeTrainer:
         self.g_group = ParamGroup([model.decoder, model.vq_estimator, model.fusion_module], dev)
         self.d_group = ParamGroup([discriminator], dev)
         self.g_opt, self.d_opt = Adam(self.g_group, lr_g), Adam(self.d_group, lr_d)
-        self.g_sched, self.d_sched = MultiStepLR(lr_g, list(milestones), gamma), MultiStepLR(lr_d, list(milestones), gamma)
+        # config/exp1_stage1_3.yaml:43-60: g_scheduler and d_scheduler are separate YAML entries (same values in the shipped files)
+        self.g_sched = MultiStepLR(lr_g, list(milestones), gamma)
+        self.d_sched = MultiStepLR(lr_d, list(milestones if d_milestones is None else d_milestones), gamma if d_gamma is None else d_gamma)
         self.clip = clip_max_norm
         self.w = dict(DEFAULT_LOSS)
         if loss_weights:
@@ -105,6 +120,49 @@ class DualBetaCondGanDistortionVqCodeTrainer:
         if self.w["perceptual"] > 0:
             from .lpips import LPIPSAlex
             self.lpips = LPIPSAlex(seed=0).to(dev)
+            self.lpips_is_synthetic = lpips_state is None
+            if lpips_state is not None:
+                self.load_lpips_state(lpips_state)
+
+    def load_lpips_state(self, sd: Dict[str, Tensor]) -> None:
+        """Load a state dict of the `lpips` package (LPIPS(net='alex').state_dict(): net.sliceK.I.weight/bias, linK.model.1.weight,
+        scaling_layer.shift/scale) into the perceptual network, strictly by key and shape."""
+        own = self.lpips.state_dict()
+        missing = [k for k in own if k not in sd]
+        if missing:
+            raise KeyError(f"lpips state dict lacks {missing[:4]}{'...' if len(missing) > 4 else ''}")
+        for k, v in own.items():
+            if tuple(sd[k].shape) != tuple(v.shape):
+                raise ValueError(f"lpips state dict: {k} has shape {tuple(sd[k].shape)}, expected {tuple(v.shape)}")
+            v.copy_(sd[k].to(v.device, dtype=v.dtype))
+        for m in self.lpips.modules():
+            if hasattr(m, "_plan"):
+                m._plan = None
+        self.lpips_is_synthetic = False
+
+    # ---------------------------------------------------------------- training state (base_trainer.py:178-214 saves optimizer + scheduler state)
+    def training_state(self, current_iter: int) -> Dict:
+        st = {"iter": int(current_iter), "rng": self.rng.get_state()}
+        for tag, grp, opt_, sch in (("g", self.g_group, self.g_opt, self.g_sched), ("d", self.d_group, self.d_opt, self.d_sched)):
+            st[tag] = {"m": grp.m.detach().cpu().clone(), "v": grp.v.detach().cpu().clone(), "t": int(opt_.t), "last_epoch": int(sch.last_epoch),
+                       "numel": int(grp.numel())}
+        return st
+
+    def load_training_state(self, st: Dict) -> int:
+        for tag, grp, opt_, sch in (("g", self.g_group, self.g_opt, self.g_sched), ("d", self.d_group, self.d_opt, self.d_sched)):
+            s_ = st[tag]
+            if int(s_["numel"]) != grp.numel():
+                raise ValueError(f"training state: {tag} group has {s_['numel']} parameters, this model {grp.numel()}")
+            grp.m.copy_(s_["m"].to(grp.m.device)); grp.v.copy_(s_["v"].to(grp.v.device))
+            opt_.t, sch.last_epoch = int(s_["t"]), int(s_["last_epoch"])
+        if "rng" in st:
+            self.rng.set_state(st["rng"])
+        return int(st["iter"])
+
+    def resync_parameters(self) -> None:
+        """After a state dict was loaded into the modules: parameters are views of the flat buffers, so load_state_dict's copy_
+        already wrote them; cached packed weights are stale."""
+        self.g_group.refresh_plans(); self.d_group.refresh_plans()
 
     # hyperprior_dc_vic_model.py:99-110
     def sample_selected_beta_pair(self, n: int) -> Tuple[Tensor, Tensor]:
@@ -160,7 +218,8 @@ class DualBetaCondGanDistortionVqCodeTrainer:
         o = self.generator_forward(ctx, real, vq_indices, beta_rate, beta_vq)
         g_log = self.calc_g_loss(ctx, o, beta_rate, beta_vq)
         total = sum(float(v.item()) for v in g_log.values())
-        if not math.isfinite(total) or total > 1e4:     # base_trainer.py:235-245: skip the step
+        if loss_anomaly(total, self.dist, self.device):  # base_trainer.py:235-245: skip the step -- on EVERY rank or on none
+            ctx.tape = []
             return None
         ctx.backward()
         allreduce_mean_(self.g_group.grad, self.dist)

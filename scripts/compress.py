@@ -10,7 +10,7 @@ written through pandas like the reference) and _avg_bitrate.json {"avg_bpp": mea
 MI355X additions (not in the reference, which is single-GPU, README.md:64-65):
   * --batch_size B codes B same-sized images per call (one rANS stream per image); PNG decode / encode run on
     --io_workers threads with pinned-memory staging, the next batch is decoded while the GPU codes the current one;
-  * launched under `python -m torch.distributed.run --nproc-per-node N`, the image list is sharded
+  * `--gpus N` (self-launching: N child ranks, one per GPU) or `python -m torch.distributed.run --nproc-per-node N`: the image list is sharded
     across the N GPUs (longest-processing-time-first on padded pixel count), every rank writes its own
     .bin/.png files and the per-image rows are all-gathered over RCCL so rank 0 writes the same csv /
     json a single-GPU run writes.
@@ -33,7 +33,7 @@ from dc_vic_amd import BaseConfig, build_comp_model  # noqa: E402
 from dc_vic_amd.codec_utils import load_byte_strings, save_byte_strings  # noqa: E402
 from dc_vic_amd.io_pipeline import AsyncWriter, BatchPrefetcher, encode_png_u8  # noqa: E402
 from dc_vic_amd.options import compress_arg_parser  # noqa: E402
-from dc_vic_amd.parallel import gather_rate_table, pin_rank_cpus, shard_indices  # noqa: E402
+from dc_vic_amd.parallel import gather_rate_table, launched_by_a_launcher, pin_rank_cpus, self_launch, shard_indices  # noqa: E402
 
 COLUMNS = ["img_name", "header_bit", "z_bit", "y_bit", "real_bit", "real_bpp", "pred_z_bit", "pred_y_bit", "pred_bit",
            "pred_bpp", "num_pixel"]
@@ -56,7 +56,13 @@ def main():
     p.add_argument("--batch_size", type=int, default=1)
     p.add_argument("--synthetic_weights", action="store_true")
     p.add_argument("--io_workers", type=int, default=0, help="PNG decode / encode threads (0: min(8, this rank's share of the cores))")
+    p.add_argument("--gpus", type=int, default=0, help="shard the folder over N GPUs of this node: without a launcher this process starts "
+                                                        "the N ranks itself (0: as launched -- WORLD_SIZE ranks under torch.distributed.run, else 1)")
     args = p.parse_args()
+    if args.gpus > 1 and not launched_by_a_launcher():
+        sys.exit(self_launch(args.gpus, need_gpus=args.device.startswith("cuda")))      # parent: never touches the GPU
+    if args.gpus > 0 and int(os.environ.get("WORLD_SIZE", "1")) != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={os.environ.get('WORLD_SIZE', '1')}")
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -75,7 +81,7 @@ def main():
             dist_.init_process_group("gloo", rank=rank, world_size=world)
         dist = dist_
 
-    overrides = {k: v for k, v in vars(args).items() if k not in ("batch_size", "synthetic_weights", "io_workers")}
+    overrides = {k: v for k, v in vars(args).items() if k not in ("batch_size", "synthetic_weights", "io_workers", "gpus")}
     overrides["device"] = device
     if device.startswith("cuda"):
         torch.cuda.set_device(torch.device(device))      # `-d cuda:1` makes cuda:1 the current device (kernels launch there)

@@ -12,8 +12,11 @@ all-reduces of the flat gradient buffers (the reference is single-GPU, README.md
 or seeded synthetic tensors.  Checkpoints use the reference's file format: `comp_model_iterXXXXXXX.pth.tar` =
 {'iter', 'comp_model': state_dict}, `discriminator_iter...` = {'iter', 'discriminator': state_dict} (model_saver.py:39-46).
 The optimizer / loss settings are the YAML's `optim` / `loss` sections when present (config/exp1_stage1_3.yaml:43-79), else
-their stage-3 values.  LPIPS runs on synthetic AlexNet weights unless a state dict of the `lpips` package is loaded into
-`trainer.lpips` (its weights cannot be fetched offline; see trainer.py).
+their stage-3 values (g_scheduler and d_scheduler milestones are read separately).  LPIPS: pass --lpips_path (a torch.save'd state
+dict of lpips.LPIPS(net='alex'), loaded with weights_only=True); its weights cannot be fetched offline, so without it a positive
+perceptual weight is an ERROR unless --allow_synthetic_lpips opts into synthetic AlexNet weights (benchmarks / plumbing only).
+--save_step also writes training_state_iter*.pth.tar (Adam moments, step counts, scheduler epochs, beta-sampler RNG; the
+reference saves optimizer + scheduler state too, base_trainer.py:178-214) and --resume continues from it.
 """
 from __future__ import annotations
 
@@ -29,7 +32,7 @@ import torch
 
 sys.path.append(os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 from dc_vic_amd import BaseConfig, build_comp_model  # noqa: E402
-from dc_vic_amd.parallel import pin_rank_cpus  # noqa: E402
+from dc_vic_amd.parallel import launched_by_a_launcher, pin_rank_cpus, self_launch  # noqa: E402
 from dc_vic_amd.train import DualBetaCondGanDistortionVqCodeTrainer, DualBetaCondTamingNLayerDiscriminator  # noqa: E402
 
 
@@ -92,7 +95,15 @@ def main():
     p.add_argument("--log_step", type=int, default=10)
     p.add_argument("--seed", type=int, default=0)
     p.add_argument("-d", "--device", type=str, default="cuda:0")
+    p.add_argument("--lpips_path", type=str, default=None, help="state dict of lpips.LPIPS(net='alex') (torch.save'd; loaded with weights_only=True)")
+    p.add_argument("--allow_synthetic_lpips", action="store_true", help="train the perceptual term against SYNTHETIC AlexNet / head weights (plumbing / benchmarks only)")
+    p.add_argument("--resume", type=str, default=None, help="training_state_iterXXXXXXX.pth.tar written by --save_step (loads the comp_model / discriminator files beside it)")
+    p.add_argument("--gpus", type=int, default=0, help="data-parallel over N GPUs of this node: without a launcher this process starts the N ranks itself")
     a = p.parse_args()
+    if a.gpus > 1 and not launched_by_a_launcher():
+        sys.exit(self_launch(a.gpus))                     # parent: never touches the GPU
+    if a.gpus > 0 and int(os.environ.get("WORLD_SIZE", "1")) != a.gpus:
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={os.environ.get('WORLD_SIZE', '1')}")
 
     rank, world, local_rank = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("LOCAL_RANK", "0"))
     pin_rank_cpus()
@@ -122,33 +133,62 @@ def main():
     torch.manual_seed(a.seed)                       # identical D initialisation on every rank
     D = DualBetaCondTamingNLayerDiscriminator(**dopt).to(device)
     lw = {}
-    for name, key in (("distortion", "distortion_loss"), ("gan", "gan_loss"), ("code_distortion", "code_distortion_loss"), ("code_ce", "code_ce_loss")):
+    for name, key in (("distortion", "distortion_loss"), ("perceptual", "perceptual_loss"), ("gan", "gan_loss"),
+                      ("code_distortion", "code_distortion_loss"), ("code_ce", "code_ce_loss")):
         v = _get(opt, "loss", key, "loss_weight")
         if v is not None:
             lw[name] = float(v)
+    from dc_vic_amd.train.trainer import DEFAULT_LOSS
+    w_perc = lw.get("perceptual", DEFAULT_LOSS["perceptual"])
+    lpips_state = None
+    if a.lpips_path:
+        lpips_state = torch.load(a.lpips_path, map_location="cpu", weights_only=True)
+    elif w_perc > 0:
+        msg = (f"perceptual_loss has weight {w_perc} but no --lpips_path was given: the `lpips` AlexNet / head weights cannot be fetched "
+               "offline, so the term would be computed with SYNTHETIC weights (not LPIPS).")
+        if not a.allow_synthetic_lpips:
+            raise SystemExit(msg + "  Pass --lpips_path STATE_DICT, set loss.perceptual_loss.loss_weight: 0, or opt in with --allow_synthetic_lpips.")
+        if rank == 0:
+            print("[train] WARNING: " + msg, file=sys.stderr, flush=True)
     trainer = DualBetaCondGanDistortionVqCodeTrainer(
         model, D, lr_g=float(_get(opt, "optim", "g_optimizer", "lr", default=1e-4)), lr_d=float(_get(opt, "optim", "d_optimizer", "lr", default=1e-4)),
         milestones=list(_get(opt, "optim", "g_scheduler", "milestones", default=[300000])), gamma=float(_get(opt, "optim", "g_scheduler", "gamma", default=0.1)),
         clip_max_norm=_get(opt, "optim", "clip_max_norm", default=1.0), loss_weights=lw,
-        sample_beta_batch=bool(_get(opt, "trainer", "sample_beta_batch", default=True)), dist=dist, seed=a.seed * 100 + rank)
+        sample_beta_batch=bool(_get(opt, "trainer", "sample_beta_batch", default=True)), dist=dist, seed=a.seed * 100 + rank,
+        d_milestones=_get(opt, "optim", "d_scheduler", "milestones", default=None), d_gamma=_get(opt, "optim", "d_scheduler", "gamma", default=None),
+        lpips_state=lpips_state)
+    start_iter = 0
+    if a.resume:
+        # base_trainer.py:178-214: comp_model / discriminator / training_state files of one iteration
+        st = torch.load(a.resume, map_location="cpu", weights_only=False)        # our own file (numpy RNG state inside)
+        d_ = os.path.dirname(a.resume)
+        it_tag = os.path.basename(a.resume).replace("training_state_", "")
+        model.load_state_dict(torch.load(os.path.join(d_, "comp_model_" + it_tag), map_location="cpu", weights_only=True)["comp_model"])
+        D.load_state_dict(torch.load(os.path.join(d_, "discriminator_" + it_tag), map_location="cpu", weights_only=True)["discriminator"])
+        trainer.resync_parameters()
+        start_iter = trainer.load_training_state(st)
     total_iter = a.total_iter or int(_get(opt, "total_iter", default=500000))
     data = None if a.synthetic_data else CropDataset(a.dataset_root, 256, rank, world, a.seed)
     gen = torch.Generator().manual_seed(a.seed * 7919 + rank)
     if a.save_dir and rank == 0:
         os.makedirs(a.save_dir, exist_ok=True)
+    if data is None:
+        for _ in range(start_iter):          # resume: the synthetic stream continues where the interrupted run stopped
+            torch.rand((a.batch_size, 3, 256, 256), generator=gen)
     t0 = time.perf_counter()
-    for it in range(1, total_iter + 1):
+    for it in range(start_iter + 1, total_iter + 1):
         x = (torch.rand((a.batch_size, 3, 256, 256), generator=gen) * 2 - 1) if data is None else data.batch(a.batch_size)
         log = trainer.optimize_parameters(it, {"real_images": x})
         if rank == 0 and (it % a.log_step == 0 or it == 1 or it == total_iter):
             dt = time.perf_counter() - t0
             msg = "skipped (loss anomaly)" if log is None else " ".join(f"{k} {v:.5g}" for k, v in log.items())
-            print(f"iter {it:7d} | {world * a.batch_size * it / dt:7.2f} samples/s | {msg}", flush=True)
+            print(f"iter {it:7d} | {world * a.batch_size * (it - start_iter) / dt:7.2f} samples/s | {msg}", flush=True)
         if a.save_dir and a.save_step and it % a.save_step == 0 and rank == 0:
             torch.save({"iter": it, "comp_model": {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}},
                        os.path.join(a.save_dir, f"comp_model_iter{it:07d}.pth.tar"))
             torch.save({"iter": it, "discriminator": {k: v.detach().cpu().clone() for k, v in D.state_dict().items()}},
                        os.path.join(a.save_dir, f"discriminator_iter{it:07d}.pth.tar"))
+            torch.save(trainer.training_state(it), os.path.join(a.save_dir, f"training_state_iter{it:07d}.pth.tar"))
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

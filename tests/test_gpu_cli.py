@@ -203,24 +203,41 @@ def test_binary_rate_search_script(tmp_path):
 
 
 def test_train_cli_synthetic(tmp_path):
-    """scripts/train.py (reference scripts/train.py:16-27 + train_loop): three stage-3 G + D iterations on synthetic crops, the
-    log line per iteration, and checkpoints in the reference's file format ({'iter', 'comp_model'} / {'iter', 'discriminator'})
-    that load back through load_learned_weight."""
+    """scripts/train.py (reference scripts/train.py:16-27 + train_loop): stage-3 G + D iterations on synthetic crops, the log
+    line per iteration, checkpoints in the reference's file format ({'iter', 'comp_model'} / {'iter', 'discriminator'}) that load
+    back through load_learned_weight, the lpips state-dict loader, the refusal to train against synthetic LPIPS weights
+    silently, and --resume: a run resumed from the iteration-2 training state reproduces the uninterrupted run's
+    iteration-4 weights BIT FOR BIT (Adam moments, step counts, scheduler epochs, beta-sampler RNG, data stream)."""
     import torch
-    out = tmp_path / "ckpt"
-    cmd = [sys.executable, os.path.join(ROOT, "scripts", "train.py"), os.path.join(ROOT, "config", "dc_vic_synthetic.yaml"), "--synthetic_weights",
-           "--synthetic_data", "--batch_size", "2", "--total_iter", "3", "--save_dir", str(out), "--save_step", "3", "--log_step", "1"]
-    res = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True)
+    out, out2 = tmp_path / "ckpt", tmp_path / "ckpt2"
+    base = [sys.executable, os.path.join(ROOT, "scripts", "train.py"), os.path.join(ROOT, "config", "dc_vic_synthetic.yaml"), "--synthetic_weights",
+            "--synthetic_data", "--batch_size", "2", "--log_step", "1"]
+    res = subprocess.run(base + ["--total_iter", "1"], cwd=ROOT, capture_output=True, text=True)
+    assert res.returncode != 0 and "SYNTHETIC" in res.stderr and "--lpips_path" in res.stderr, res.stderr[-2000:]
+    from dc_vic_amd.train.lpips import LPIPSAlex
+    lp = tmp_path / "lpips_alex.pth"
+    torch.save({k: v.clone() for k, v in LPIPSAlex(seed=0).state_dict().items()}, lp)      # same key names as lpips.LPIPS(net='alex')
+    res = subprocess.run(base + ["--total_iter", "4", "--save_dir", str(out), "--save_step", "2", "--lpips_path", str(lp)], cwd=ROOT, capture_output=True, text=True)
     assert res.returncode == 0, res.stderr[-2000:]
     lines = [ln for ln in res.stdout.splitlines() if ln.startswith("iter")]
-    assert len(lines) == 3 and all("samples/s" in ln and "distortion" in ln and "perceptual" in ln and "d_total" in ln for ln in lines), res.stdout
-    ck = torch.load(out / "comp_model_iter0000003.pth.tar", map_location="cpu", weights_only=True)
-    assert ck["iter"] == 3 and "decoder.conv1.weight" in ck["comp_model"] and "vq_model.decoder.conv_in.weight" in ck["comp_model"]
-    dk = torch.load(out / "discriminator_iter0000003.pth.tar", map_location="cpu", weights_only=True)
+    assert len(lines) == 4 and all("samples/s" in ln and "distortion" in ln and "perceptual" in ln and "d_total" in ln for ln in lines), res.stdout
+    ck = torch.load(out / "comp_model_iter0000004.pth.tar", map_location="cpu", weights_only=True)
+    assert ck["iter"] == 4 and "decoder.conv1.weight" in ck["comp_model"] and "vq_model.decoder.conv_in.weight" in ck["comp_model"]
+    dk = torch.load(out / "discriminator_iter0000004.pth.tar", map_location="cpu", weights_only=True)
     assert sorted(k for k in dk["discriminator"] if k.startswith("main.")) == [f"main.{i}.{p}" for i in (0, 11, 2, 5, 8) for p in ("bias", "weight")]
+    res2 = subprocess.run(base + ["--total_iter", "4", "--save_dir", str(out2), "--save_step", "4", "--lpips_path", str(lp),
+                                  "--resume", str(out / "training_state_iter0000002.pth.tar")], cwd=ROOT, capture_output=True, text=True)
+    assert res2.returncode == 0, res2.stderr[-2000:]
+    lines2 = [ln for ln in res2.stdout.splitlines() if ln.startswith("iter")]
+    assert len(lines2) == 2 and lines2[0].split("|")[0].split() == ["iter", "3"]
+    assert [ln.split("|")[2] for ln in lines2] == [ln.split("|")[2] for ln in lines[2:]], (lines2, lines[2:])       # same losses, digit for digit
+    ck2 = torch.load(out2 / "comp_model_iter0000004.pth.tar", map_location="cpu", weights_only=True)
+    dk2 = torch.load(out2 / "discriminator_iter0000004.pth.tar", map_location="cpu", weights_only=True)
+    assert all(torch.equal(ck["comp_model"][k], ck2["comp_model"][k]) for k in ck["comp_model"])
+    assert all(torch.equal(dk["discriminator"][k], dk2["discriminator"][k]) for k in dk["discriminator"])
     from dc_vic_amd import BaseConfig, build_comp_model
     m = build_comp_model(BaseConfig.fromfile(os.path.join(ROOT, "config", "dc_vic_synthetic.yaml"), {"device": "cuda:0"}))
-    m.load_learned_weight(str(out / "comp_model_iter0000003.pth.tar"))
+    m.load_learned_weight(str(out / "comp_model_iter0000004.pth.tar"))
     from dc_vic_amd.synth import full_synth_state_dict
     sd = full_synth_state_dict(1234)
     assert torch.equal(m.state_dict()["encoder.conv1.weight"].cpu(), sd["encoder.conv1.weight"])            # frozen: untouched

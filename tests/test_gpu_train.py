@@ -361,6 +361,67 @@ def test_generator_and_discriminator_step_vs_oracle(model, synth_sd):
             assert float((da - db)[big].abs().max()) <= 2e-2 * 1e-4, k
 
 
+def test_generator_gradient_at_step2_uses_updated_discriminator(model, synth_sd):
+    """inside the generator step the discriminator is not trainable, so its data-gradient plans (flipped /
+    transposed weight copies) are cached on the modules; after the D Adam step they must be rebuilt.  GAN-only loss weights
+    and a large D learning rate make the adversarial gradient the whole gradient and move D's weights by ~40 % in one step:
+    the generator gradients of the SECOND iteration are compared with torch autograd over the oracle evaluated at the
+    product's post-step-1 weights.  With a stale plan they are off by tens of percent."""
+    from dc_vic_amd.train import DualBetaCondGanDistortionVqCodeTrainer
+    from dc_vic_amd.train import autograd as A
+    from oracle import train_oracle as T
+    from oracle.entropy_oracle import EntropyBottleneckOracle
+    sd_before = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    try:
+        D = _disc(5).to(DEV)
+        w = dict(distortion=0.0, perceptual=0.0, gan=1.0, code_distortion=0.0, code_ce=0.0)
+        tr = DualBetaCondGanDistortionVqCodeTrainer(model, D, lr_g=1e-5, lr_d=2e-2, clip_max_norm=None, loss_weights=w, seed=3)
+        x = torch.rand((2, 3, 64, 64), generator=torch.Generator().manual_seed(93)) * 2 - 1
+        b1, b2 = torch.tensor([2.29, 0.62]), torch.tensor([3.0, 1.5])
+        d0 = D.main[2].weight.detach().clone()
+        assert tr.optimize_parameters(0, dict(real_images=x, beta_rate=b1, beta_vq=b2)) is not None
+        moved = float((D.main[2].weight - d0).abs().mean() / d0.abs().mean())
+        assert moved > 0.2, moved                      # the D step really changed the weights the G step back-propagates through
+        # ---- oracle at the product's current weights
+        sd = {k: v.clone() for k, v in synth_sd.items()}
+        for k, v in model.state_dict().items():
+            if k in sd and sd[k].is_floating_point():
+                sd[k] = v.detach().cpu().clone()
+        names = [k for k in sd if k.startswith(T.TRAINABLE_PREFIXES) and sd[k].is_floating_point()]
+        for k in names:
+            sd[k].requires_grad_(True)
+        dsd = {k: v.detach().cpu().clone() for k, v in D.state_dict().items()}
+        eb = EntropyBottleneckOracle(synth_sd, "entropy_model_z")
+        L, oo = T.generator_losses(sd, dsd, x, b1, b2, eb, w=w)
+        sum(L.values()).backward()
+        # ---- product: second iteration's forward / backward
+        tr.g_group.zero_grad()
+        ctx = A.Ctx([tr.g_group])
+        o = tr.generator_forward(ctx, x, None, b1, b2)
+        glog = tr.calc_g_loss(ctx, o, b1, b2)
+        relclose(glog["adv"], L["adv"].detach().reshape(1), 2e-4, "adv loss at step 2")
+        ctx.backward()
+        own = dict(model.named_parameters())
+        checked, worst = 0, 0.0
+        for k in names:
+            gref = sd[k].grad
+            if gref is None or float(gref.abs().max()) == 0.0:
+                continue
+            worst = max(worst, relclose(tr.g_group.grad_of(own[k]), gref, 3e-3, f"step-2 grad {k}"))
+            checked += 1
+        assert checked >= 100, checked                 # fusion blocks + ELIC decoder taps (the estimator sits behind the argmax)
+        print(f"[train parity] step-2 generator gradients through the updated D: {checked} tensors, worst relative error {worst:.2e}")
+    finally:
+        model.load_state_dict(sd_before)               # the fixture is shared: put the synthetic weights back
+        for m in model.modules():
+            if hasattr(m, "_plan"):
+                m._plan = None
+            if hasattr(m, "_qkv_plan"):
+                m._qkv_plan = None
+            if hasattr(m, "invalidate_caches"):
+                m.invalidate_caches()
+
+
 def test_training_steps_256_and_checkpoint(model, tmp_path):
     """BASELINE config 5's sample shape (256x256 crops), per-sample beta pairs drawn by the trainer: a few G + D steps run, every
     logged quantity is finite, the generator and discriminator weights move, the frozen sub-networks do not, the updated

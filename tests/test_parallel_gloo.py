@@ -116,3 +116,87 @@ def test_bucketed_gradient_allreduce_world2(tmp_path):
     for _ in range(7):
         lrs.append(sch.lr()); sch.step()
     assert np.allclose(lrs, [1e-4] * 3 + [1e-5] * 2 + [1e-6] * 2)
+
+
+# ------------------------------------------------------------------------------------------- `--gpus N` self-launch
+def _run(cmd, timeout=300):
+    import subprocess
+    import sys
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "LOCAL_WORLD_SIZE", "MASTER_PORT", "TORCHELASTIC_RUN_ID"):
+        env.pop(k, None)
+    return subprocess.run([sys.executable] + cmd, env=env, capture_output=True, text=True, timeout=timeout)
+
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_self_launch_starts_n_ranks_gloo():
+    """`prog --gpus 2` with no launcher in the environment must itself become two ranks: the spawner sets
+    RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*, rank 0 prints the one result line with n_gpus = 2, exit code 0."""
+    import json
+    r = _run([os.path.join(ROOT, "tests", "_spawn_probe.py"), "--gpus", "2"])
+    assert r.returncode == 0, r.stderr
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    assert out == {"n_gpus": 2, "rows": [float(i) for i in range(7)], "self_launched": True, "local_world": "2"}
+    r1 = _run([os.path.join(ROOT, "tests", "_spawn_probe.py"), "--gpus", "1"])         # N = 1: no children, plain run
+    assert r1.returncode == 0 and json.loads(r1.stdout.strip())["self_launched"] is False
+
+
+def test_self_launch_propagates_a_rank_failure():
+    """One rank dying must end the job with its exit code instead of leaving the others in a collective forever."""
+    r = _run([os.path.join(ROOT, "tests", "_spawn_probe.py"), "--gpus", "2", "--fail_rank", "1"], timeout=120)
+    assert r.returncode == 7
+
+
+def test_gpus_n_without_devices_fails_loudly():
+    """With fewer HIP devices than --gpus asks for, bench.py / compress.py / train.py exit non-zero and say why -- never a
+    1-rank run reported as the answer (and never a CPU fallback).  Runs wherever fewer than 2 devices are visible."""
+    if torch.cuda.device_count() >= 2:
+        import pytest
+        pytest.skip("needs a node with < 2 HIP devices")
+    for cmd in ([os.path.join(ROOT, "bench.py"), "--gpus", "2"],
+                [os.path.join(ROOT, "scripts", "compress.py"), "--config_path", os.path.join(ROOT, "config", "dc_vic_synthetic.yaml"),
+                 "--img_dir", ROOT, "--save_dir", "/tmp/_dcvic_never", "--gpus", "2", "--synthetic_weights", "-q", "0"],
+                [os.path.join(ROOT, "scripts", "train.py"), os.path.join(ROOT, "config", "dc_vic_synthetic.yaml"), "--gpus", "2", "--synthetic_weights",
+                 "--synthetic_data"]):
+        r = _run(cmd)
+        assert r.returncode != 0
+        assert "--gpus 2 requested but this node exposes" in r.stderr, r.stderr
+        assert not any(ln.startswith("{") for ln in r.stdout.splitlines())
+    # a launcher that disagrees with --gpus is an error too
+    import subprocess
+    import sys
+    env = dict(os.environ, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "WORLD_SIZE=1" in r.stderr
+
+
+def _anomaly_worker(rank, world, port, out_dir):
+    import json
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from dc_vic_amd.train.trainer import loss_anomaly
+    res = [loss_anomaly(float("inf") if rank == 1 else 3.0, dist),      # one rank sees an inf loss
+           loss_anomaly(2.0e4 if rank == 0 else 1.0, dist),             # one rank above the 1e4 threshold
+           loss_anomaly(5.0 + rank, dist)]                               # healthy everywhere
+    with open(os.path.join(out_dir, f"anom{rank}.json"), "w") as f:
+        json.dump(res, f)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_loss_anomaly_skip_is_collective_world2(tmp_path):
+    """the reference's loss-anomaly skip (base_trainer.py:235-245) decided per rank would leave the healthy ranks
+    blocked in the gradient all-reduce.  The decision is one MAX all-reduce: every rank skips or none does."""
+    import json
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    mp.spawn(_anomaly_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    a, b = (json.load(open(tmp_path / f"anom{r}.json")) for r in (0, 1))
+    assert a == b == [True, True, False]
+    from dc_vic_amd.train.trainer import loss_anomaly
+    assert loss_anomaly(float("nan"), None) and loss_anomaly(1.0e5, None) and not loss_anomaly(12.0, None)
