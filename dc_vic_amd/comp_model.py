@@ -43,6 +43,9 @@ Tensor = torch.Tensor
 SPLIT_DECODE_RESOLUTION = 1024   # hyperprior_vic_model.py:25-27
 SPLIT_WINDOW_SIZE = 512
 SPLIT_STRIDE = 256
+# tiling windows of a > 1024-px image decoded / encoded per kernel launch (the reference loops one by one): 32 x 512^2 windows
+# are ~25 GB of activations at the VQGAN decoder's widest point -- nothing on a 288 GB part
+TILE_BATCH = max(1, int(os.environ.get("DCVIC_TILE_BATCH", "32")))
 
 
 class _GraphCache:
@@ -309,6 +312,10 @@ class HyperpriorVicModel(BaseModel):
 
     # ------------------------------------------------------------------ VQ encode (137-246)
     def _vq_encode_split(self, real_images: Tensor) -> Tensor:
+        """hyperprior_vic_model.py:190-246: 512-px windows, stride 256, centre regions stitched.  The reference encodes the windows
+        one by one; here up to TILE_BATCH of them are stacked into ONE encoder call (the windows are independent and every kernel
+        is batch-invariant, so the stitched latent is bit-identical to the window-by-window loop -- asserted in test_tiling_vs_oracle):
+        a 1280x2048 image is one 28-window batch in the batch-32 regime instead of 28 launches in the N=1 regime."""
         N, _, H, W = real_images.shape
         stride, patch = SPLIT_STRIDE, SPLIT_WINDOW_SIZE
         df = 2 ** (self.vq_model.encoder.num_resolutions - 1)
@@ -316,11 +323,16 @@ class HyperpriorVicModel(BaseModel):
         lefts = _starts(W, stride, patch, True)
         tops = _starts(H, stride, patch, True)
         z_out = torch.zeros((N, ndim, H // df, W // df), dtype=torch.float32, device=real_images.device)
-        crop = torch.empty((N, real_images.shape[1], patch, patch), dtype=torch.float32, device=real_images.device)
-        for y0 in tops:
-            for x0 in lefts:
-                ops.copy_window(crop, real_images[:, :, y0:y0 + patch, x0:x0 + patch])
-                z = self.vq_model.encode(crop)
+        wins = [(y0, x0) for y0 in tops for x0 in lefts]
+        per = max(1, TILE_BATCH // N)
+        for c0 in range(0, len(wins), per):
+            chunk = wins[c0:c0 + per]
+            crop = torch.empty((N * len(chunk), real_images.shape[1], patch, patch), dtype=torch.float32, device=real_images.device)
+            for k, (y0, x0) in enumerate(chunk):
+                ops.copy_window(crop[k * N:(k + 1) * N], real_images[:, :, y0:y0 + patch, x0:x0 + patch])
+            zb = self.vq_model.encode(crop)
+            for k, (y0, x0) in enumerate(chunk):
+                z = zb[k * N:(k + 1) * N]
                 off = (stride // 2) // df
                 _x0, _y0 = x0 // df, y0 // df
                 l = _x0 + off if x0 > 0 else 0
@@ -377,17 +389,24 @@ class HyperpriorVicModel(BaseModel):
         return img, idx
 
     def decode_split(self, y_hat: Tensor, fuse_w: float, **kwargs) -> Tensor:
+        """hyperprior_vic_model.py:413-473: 32x32-latent windows (512 px), stride 16, centre regions stitched into a buffer pre-filled
+        with -100.  Windows are decoded as batches of up to TILE_BATCH (see _vq_encode_split): same bits, batch-32 regime."""
         N, _, yH, yW = y_hat.shape
         df = 16
         stride, patch = SPLIT_STRIDE // df, SPLIT_WINDOW_SIZE // df
         lefts = _starts(yW, stride, patch, False)
         tops = _starts(yH, stride, patch, False)
         out = torch.full((N, 3, yH * df, yW * df), -100.0, dtype=torch.float32, device=y_hat.device)
-        crop = torch.empty((N, y_hat.shape[1], patch, patch), dtype=torch.float32, device=y_hat.device)
-        for y0 in tops:
-            for x0 in lefts:
-                ops.copy_window(crop, y_hat[:, :, y0:y0 + patch, x0:x0 + patch])
-                o, _ = self._decode(crop, w=fuse_w, **kwargs)
+        wins = [(y0, x0) for y0 in tops for x0 in lefts]
+        per = max(1, TILE_BATCH // N)
+        for c0 in range(0, len(wins), per):
+            chunk = wins[c0:c0 + per]
+            crop = torch.empty((N * len(chunk), y_hat.shape[1], patch, patch), dtype=torch.float32, device=y_hat.device)
+            for k, (y0, x0) in enumerate(chunk):
+                ops.copy_window(crop[k * N:(k + 1) * N], y_hat[:, :, y0:y0 + patch, x0:x0 + patch])
+            ob, _ = self._decode(crop, w=fuse_w, **kwargs)
+            for k, (y0, x0) in enumerate(chunk):
+                o = ob[k * N:(k + 1) * N]
                 off = (stride // 2) * df
                 _x0, _y0 = x0 * df, y0 * df
                 l = _x0 + off if x0 > 0 else 0

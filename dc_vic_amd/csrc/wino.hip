@@ -12,10 +12,10 @@
 //
 // One PERSISTENT workgroup per CU = 512 threads = 8 waves (2 per SIMD); a tile is 64 output channels x (8 rows x 32 columns)
 // = 64 tiles of 2x2, all stages of all its tiles one continuous stream.
-//   * a pipeline stage is 8 input channels.  Per stage the raw input patch (8 ch x 10 rows x ten 16-byte segments, zero
-//     padded through a zero source) and the pre-transformed weights U (16 positions x 8 ch x 64 co = 32 KiB, packed by
+//   * a pipeline stage is 8 input channels.  Per stage the raw input patch (8 ch x (10 rows x ten 16-byte segments + 2 of padding),
+//     zero padded through a zero source) and the pre-transformed weights U (16 positions x 8 ch x 64 co = 32 KiB, packed by
 //     wino_pack_kernel in the exact LDS image) arrive by LDS-DMA (`global_load_lds_dwordx4`), two stages / one stage ahead;
-//   * every thread transforms ONE (channel, tile) 4x4 patch per stage (8 ds_read2_b32, 32 adds, 8 ds_write2st64_b32) into the
+//   * every thread transforms ONE (channel, tile) 4x4 patch per stage (12 conflict-free ds_read_b64, 32 adds, 8 ds_write2st64_b32) into the
 //     V image of the NEXT stage, its instructions placed behind the MFMAs of the current stage;
 //   * wave w = (co group cg = w % 4 of 16 channels, tile half th = w / 4 of 32 tiles) owns ALL 16 Winograd positions of its
 //     16 x 32 block: per position two `v_mfma_f32_16x16x4_f32` accumulators (128 accumulator registers per lane), fed by
@@ -40,8 +40,9 @@ __device__ float dcvic_wino_zero[16];   // zero-initialised: source of padded la
 #define WN_TH 8
 #define WN_TW 32
 #define WN_PW 40          // LDS row: columns ox0 - 4 .. ox0 + 35 as ten 16-byte segments; the patch's 34 columns sit at 3 .. 36
-#define WN_PLANE 400
-#define WN_SEGS 800        // float4 segments of a stage: 8 ch x 10 rows x 10
+#define WN_PLANE 408       // 102 segments per channel plane: 100 of data + 2 of padding, so that FOUR planes are 32 (mod 64) banks apart (see t_load)
+#define WN_PSEGS 102
+#define WN_SEGS 816        // float4 segments of a stage: 8 ch x (10 rows x 10 + 2)
 #define WN_CO 64
 #define WN_THREADS 512
 #define WN_XSLOTS 2
@@ -147,10 +148,10 @@ __global__ __launch_bounds__(WN_THREADS, 2) void conv3x3_wino_kernel(const ConvK
             const int e = tid + s * WN_THREADS;                    // float4 segment e of [8 ch][10 rows][10 segments]
             int o = -1;
             if (e < WN_SEGS) {
-                const int k = e / 100, r = e - k * 100;
+                const int k = e / WN_PSEGS, r = e - k * WN_PSEGS;  // (r >= 100: the plane's two padding segments, fed from the zero word)
                 const int py = r / 10, seg = r - py * 10;
                 const int iy = iy0 + py, ix = ix0 - 3 + 4 * seg;   // W % 4 == 0: a segment is entirely inside or outside the row
-                if (iy >= 0 && iy < K.H && ix >= 0 && ix < K.W) o = (int)(k * HW) + iy * K.W + ix;
+                if (r < 100 && iy >= 0 && iy < K.H && ix >= 0 && ix < K.W) o = (int)(k * HW) + iy * K.W + ix;
             }
             poff[s] = o;
         }
@@ -167,10 +168,15 @@ __global__ __launch_bounds__(WN_THREADS, 2) void conv3x3_wino_kernel(const ConvK
     };
     u_setup(first);
     // ---- input transform: this thread's (channel, tile) of a stage
-    //   wave -> (th, k); lane -> (n, blk, ks);  channel 4ks + k, tile row 2th + blk, tile column n
+    //   wave -> (th, k); lane -> (n, ks, blk);  channel 4ks + k, tile row 2th + blk, tile column n.
+    //   The patch's four columns 2n + 3 .. 2n + 6 start on an ODD dword (16-byte DMA segments of a pad-1 convolution), so dword reads
+    //   of a 32-lane group can only ever touch the 16 odd (or even) banks: a 2-way conflict on every access (28.5 % of the LDS cycles
+    //   of the round-2 build).  They are fetched instead as THREE aligned 8-byte pairs (2n + 2 .. 2n + 7; `ds_read_b64`: 64 banks per
+    //   32-lane group): lanes 0..15 of a group cover banks 2 .. 33 and lanes 16..31 hold the channel four planes further
+    //   (4 x 408 dwords = 32 mod 64): conflict-free.
     const int t_th = wave >> 2, t_k = wave & 3;
-    const int t_n = lane & 15, t_blk = (lane >> 4) & 1, t_ks = lane >> 5;
-    const unsigned t_src = 4u * (unsigned)((4 * t_ks + t_k) * WN_PLANE + (2 * (2 * t_th + t_blk)) * WN_PW + 2 * t_n + 3);
+    const int t_n = lane & 15, t_ks = (lane >> 4) & 1, t_blk = lane >> 5;
+    const unsigned t_src = 4u * (unsigned)((4 * t_ks + t_k) * WN_PLANE + (2 * (2 * t_th + t_blk)) * WN_PW + 2 * t_n + 2);
     const unsigned t_dst = 4u * (unsigned)(WN_OFF_V + ((t_th * 4 + t_k) * 16 + t_n) * 4 + t_blk * 2 + t_ks);
     // ---- MFMA operands: wave -> (cg = co group, th = tile half)
     const int cg = wave & 3, th = wave >> 2;
@@ -193,19 +199,20 @@ __global__ __launch_bounds__(WN_THREADS, 2) void conv3x3_wino_kernel(const ConvK
 #define WN_WAIT_LDS() do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); WN_FENCE(); } while (0)
     // raw 4x4 patch of the transform.  The asm loads write the very variables t_compute reads after the wait: a copy made
     // between a load and the `s_waitcnt` would read the register before the LDS data has landed.
-    f32x2 tlo[4], thi[4];
+    f32x2 tp0[4], tp1[4], tp2[4];                                 // row r: dwords (2n+2, 2n+3) | (2n+4, 2n+5) | (2n+6, 2n+7); the patch is the middle four
     float td[4][4];
-    auto t_load = [&](auto r_, unsigned xaddr) {                  // row r of the patch: two dword pairs
+    auto t_load = [&](auto r_, unsigned xaddr) {                  // row r of the patch: three aligned dword pairs
         constexpr int r = decltype(r_)::value;
-        f32x2 &lo = tlo[r], &hi = thi[r];                         // (odd dword offset: two dwords per read instead of one ds_read_b64)
-        asm volatile("ds_read2_b32 %0, %1 offset0:%2 offset1:%3" : "=v"(lo) : "v"(xaddr), "n"(r * WN_PW), "n"(r * WN_PW + 1));
-        asm volatile("ds_read2_b32 %0, %1 offset0:%2 offset1:%3" : "=v"(hi) : "v"(xaddr), "n"(r * WN_PW + 2), "n"(r * WN_PW + 3));
+        f32x2 &p0 = tp0[r], &p1 = tp1[r], &p2 = tp2[r];
+        asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(p0) : "v"(xaddr), "n"(4 * (r * WN_PW)));
+        asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(p1) : "v"(xaddr), "n"(4 * (r * WN_PW + 2)));
+        asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(p2) : "v"(xaddr), "n"(4 * (r * WN_PW + 4)));
     };
     float tv[16];
     auto t_compute = [&](auto c_) {                               // column c of B^T d, then nothing else: rows are finished in t_rows
         constexpr int c = decltype(c_)::value;
-        const float d0 = c < 2 ? tlo[0][c & 1] : thi[0][c & 1], d1 = c < 2 ? tlo[1][c & 1] : thi[1][c & 1];
-        const float d2 = c < 2 ? tlo[2][c & 1] : thi[2][c & 1], d3 = c < 2 ? tlo[3][c & 1] : thi[3][c & 1];
+        auto col = [&](int r) __attribute__((always_inline)) { return c == 0 ? tp0[r][1] : c == 1 ? tp1[r][0] : c == 2 ? tp1[r][1] : tp2[r][0]; };
+        const float d0 = col(0), d1 = col(1), d2 = col(2), d3 = col(3);
         td[0][c] = d0 - d2; td[1][c] = d1 + d2; td[2][c] = d2 - d1; td[3][c] = d1 - d3;
     };
     auto t_rows = [&](auto a_) {                                  // row a of (B^T d) B

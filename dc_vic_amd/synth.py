@@ -180,3 +180,16 @@ def load_synth_weights(model, seed: int = 1234) -> Dict[str, torch.Tensor]:
     merged = {k: (sd[k] if k in sd else v) for k, v in own.items()}
     model.load_state_dict(merged)
     return sd
+
+
+def synth_discriminator_state(shapes: Dict[str, Iterable], seed: int = 5) -> Dict[str, torch.Tensor]:
+    """Deterministic PatchGAN weights for fixtures and tests: name -> shape in, name -> tensor out, drawn in SORTED key order from one
+    CPU generator (so the reference module in oracle/gen_golden.py and the product module get bit-identical values without the
+    11 MB state dict being committed).  N(0, 0.05) matrices / kernels, N(0, 0.02) biases -- a bit larger than taming's
+    weights_init N(0, 0.02) so the logits carry signal."""
+    g = torch.Generator().manual_seed(int(seed))
+    out = {}
+    for name in sorted(shapes):
+        shp = tuple(int(v) for v in shapes[name])
+        out[name] = torch.randn(shp, generator=g) * (0.05 if len(shp) > 1 else 0.02)
+    return out

@@ -151,6 +151,64 @@ def gen_charm(mods):
     np.savez_compressed(os.path.join(OUT, "charm.npz"), **C)
 
 
+def gen_train():
+    """tests/golden/train.npz -- the a20 pieces the reference lets us import: the stage-3 PatchGAN
+    `DualBetaCondTamingNLayerDiscriminator` (dual_beta_taming_nlayer_discriminator.py:16-89 over taming_nlayer_discriminator.py:29-119,
+    built with the kwargs of config/exp1_stage1_3.yaml:28-41) and the four loss modules of config/exp1_stage1_3.yaml:61-79 with
+    their YAML kwargs: MSELoss(50, normalize_img, '0_1'), VanillaGANLoss(0.01), VanillaMSELoss(1.0), CrossEntropyLoss(0.5)
+    (src/losses/distortion_loss.py:10-49, gan_loss.py:10-32, cross_entropy_loss.py:10-28).  Weights: dc_vic_amd.synth.
+    synth_discriminator_state(shapes, seed 5) loaded with strict=True (the fixture stores the key -> shape manifest, not the 11 MB
+    of weights).  Stored: D logits for a per-sample-beta batch and a scalar-beta batch, every loss value the trainer computes from
+    them (calc_g_loss / calc_d_loss, dual_cond_gan_distortion_vq_code_trainer.py:192-300: generator adv, D real x 0.5, D fake x 0.5),
+    d(adv)/d(image) by torch autograd through the reference modules, and the code / distortion losses on seeded tensors.
+    LPIPS (perceptual_loss.py) needs the `lpips` wheel + downloaded weights: not importable, stays parity unpinned."""
+    ref_loader.install_training_names()
+    from dc_vic_amd.synth import synth_discriminator_state
+    top = yaml.safe_load(open(os.path.join(ref_loader.REF, "config/exp1_stage1_3.yaml")))
+    with contextlib.redirect_stdout(io.StringIO()):
+        dm = ref_loader.ref("src.models.discriminator.dual_beta_taming_nlayer_discriminator")
+        gl = ref_loader.ref("src.losses.gan_loss")
+        cl = ref_loader.ref("src.losses.cross_entropy_loss")
+        dl = ref_loader.ref("src.losses.distortion_loss")
+    dcfg = dict(top["discriminator"]); assert dcfg.pop("type") == "DualBetaCondTamingNLayerDiscriminator"
+    D = dm.DualBetaCondTamingNLayerDiscriminator(**dcfg).eval()
+    shapes = {k: tuple(v.shape) for k, v in D.state_dict().items()}
+    D.load_state_dict(synth_discriminator_state(shapes, 5), strict=True)
+    lcfg = {k: dict(v) for k, v in top["loss"].items()}
+    for v in lcfg.values():
+        v.pop("type")
+    gan = gl.VanillaGANLoss(**lcfg["gan_loss"])
+    mse = dl.MSELoss(**lcfg["distortion_loss"])
+    vmse = dl.VanillaMSELoss(**lcfg["code_distortion_loss"])
+    ce = cl.CrossEntropyLoss(**lcfg["code_ce_loss"])
+    G = {"d_manifest": json.dumps({k: list(v) for k, v in shapes.items()}, sort_keys=True), "d_seed": np.int64(5),
+         "d_kwargs": json.dumps(dcfg, sort_keys=True), "loss_kwargs": json.dumps(lcfg, sort_keys=True)}
+    real, fake = img((2, 3, 64, 64), 71), img((2, 3, 64, 64), 72)
+    b1, b2 = torch.tensor([2.29, 0.62]), torch.tensor([3.0, 1.5])
+    G["real"], G["fake"], G["beta_1"], G["beta_2"] = real.numpy(), fake.numpy(), b1.numpy(), b2.numpy()
+    fk = fake.clone().requires_grad_(True)
+    g_fake = D(fk, beta_1=b1, beta_2=b2, y_hat=None)
+    adv = gan(g_fake, is_real=True, is_disc=False)
+    adv.backward()
+    G["d_fake_logits"], G["adv_loss"], G["adv_grad_fake"] = g_fake.detach().numpy(), adv.detach().numpy(), fk.grad.numpy()
+    with torch.no_grad():
+        d_real = D(real, beta_1=b1, beta_2=b2, y_hat=None)
+        G["d_real_logits"] = d_real.numpy()
+        G["d_loss_real"] = (gan(d_real, is_real=True, is_disc=True) * 0.5).numpy()
+        G["d_loss_fake"] = (gan(g_fake.detach(), is_real=False, is_disc=True) * 0.5).numpy()
+        # scalar betas (the q-indexed pair a validation step passes, hyperprior_dc_vic_model.py:99-110)
+        G["d_real_logits_scalar_beta"] = D(real, beta_1=1.51, beta_2=2.25, y_hat=None).numpy()
+        G["distortion_loss"] = mse(real, fake).numpy()
+    lg = rnd((2, 256, 8, 8), 73, 2.0).requires_grad_(True)
+    tgt = torch.randint(0, 256, (2, 8, 8), generator=torch.Generator().manual_seed(74))
+    l_ce = ce(lg, tgt); l_ce.backward()
+    G["ce_logits"], G["ce_target"], G["ce_loss"], G["ce_grad"] = lg.detach().numpy(), tgt.numpy(), l_ce.detach().numpy(), lg.grad.numpy()
+    a, b = rnd((2, 4, 8, 8), 75), rnd((2, 4, 8, 8), 76)
+    G["code_a"], G["code_b"], G["code_distortion_loss"] = a.numpy(), b.numpy(), vmse(a, b).numpy()
+    np.savez_compressed(os.path.join(OUT, "train.npz"), **G)
+    print("train.npz:", {k: (v.shape if hasattr(v, "shape") else v) for k, v in G.items() if not isinstance(v, str)})
+
+
 @torch.no_grad()
 def main():
     torch.set_num_threads(8)
@@ -235,6 +293,8 @@ def main():
     np.savez_compressed(os.path.join(OUT, "stages.npz"), **G)
 
     gen_charm(mods)
+    with torch.enable_grad():
+        gen_train()
 
     # --- a13 wire format from the reference's own codec_utils
     cu = ref_loader.ref("src.utils.codec_utils")
@@ -259,4 +319,7 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "train":      # only the a20 fixture
+        gen_train()
+    else:
+        main()

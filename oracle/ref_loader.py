@@ -135,6 +135,26 @@ def install_compressai_names():
     sys.modules["compressai.entropy_models"] = em
 
 
+def install_training_names():
+    """For the a20 fixtures (tests/golden/train.npz): path-only packages for `src.models.discriminator` and `src.losses` (their
+    __init__.py glob-import every sibling, among them files that need lpips / pytorch_msssim) and ONE name-only placeholder:
+      * pytorch_msssim.MS_SSIM -- imported at module level by src/losses/distortion_loss.py:6, used only by the MS-SSIM loss
+        class of that file (never instantiated here: the fixture drives MSELoss and VanillaMSELoss).  It raises when used.
+    The discriminator and loss classes themselves are the reference's own code, imported from /root/reference."""
+    install()
+    for name in ["src.models.discriminator", "src.losses"]:
+        if name not in sys.modules:
+            _pkg(name, os.path.join(REF, *name.split(".")))
+    if "pytorch_msssim" not in sys.modules:
+        class _NameOnly:
+            def __init__(self, *a, **k):
+                raise RuntimeError("pytorch_msssim is not installed: this is a name-only placeholder (oracle/ref_loader.py)")
+        pm = types.ModuleType("pytorch_msssim")
+        pm.MS_SSIM = type("MS_SSIM", (_NameOnly,), {})
+        pm.__dcvic_name_only__ = True
+        sys.modules["pytorch_msssim"] = pm
+
+
 def ref(modname):
     install()
     return importlib.import_module(modname)

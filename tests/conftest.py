@@ -67,3 +67,16 @@ def demo_image(name):
     a = np.asarray(Image.open(os.path.join(GOLDEN, "demo_images", name)).convert("RGB"), dtype=np.uint8)
     x = torch.from_numpy(a.copy()).permute(2, 0, 1).float().div(255.0)
     return ((x - 0.5) / 0.5).unsqueeze(0)
+
+
+@pytest.fixture(scope="session")
+def train_golden():
+    """tests/golden/train.npz: PatchGAN logits + the stage-3 loss values from the reference's own modules (oracle/gen_golden.py:gen_train)."""
+    import numpy as np
+    return np.load(os.path.join(GOLDEN, "train.npz"))
+
+
+def train_golden_disc_state(G):
+    """The discriminator weights the fixture was generated with: regenerated from its key -> shape manifest and seed."""
+    from dc_vic_amd.synth import synth_discriminator_state
+    return synth_discriminator_state(json.loads(str(G["d_manifest"])), int(G["d_seed"]))

@@ -11,7 +11,10 @@ unconditional: a difference upstream cannot hide (or excuse) a difference downst
  * bytes: the product's C++ rANS coder on the oracle's symbols / cdf indexes must reproduce the oracle's
    strings byte for byte, and the free-running product bitstream must equal the oracle's whenever no
    near-tie was itemised.
-The report also records the measured errors so tolerances can be audited (gpurun_out/parity_report.json).
+   The NUMBER of itemised near-ties per decision class and case is capped (CAP_RATE): a less accurate kernel widens the
+   per-element bounds and would otherwise "explain" more flips and stay green.
+The report also records the measured errors, the near-tie counts and their caps so tolerances can be audited
+(gpurun_out/parity_report.json).
 """
 from __future__ import annotations
 
@@ -40,6 +43,14 @@ TOL = {
 }
 
 
+# Cap on itemised near-ties per (case, decision class): cap = max(1, ceil(rate * decisions)).  Rates = ~3x the worst rate measured
+# over every round-2 / round-3 case (profiles/r2_parity_report.json: VQ index 1 of 9 792 = 1.0e-4 on the tiled image; cdf index 1 of
+# 294 912 = 3.4e-6 on kodim23 q4; symbols 0; estimator argmax 0 of 6 144).  An fp32 summation-order difference of 1e-7 relative
+# against decision margins that are ~uniform puts the expected rate at 1e-6 .. 1e-5, so these caps leave room for nothing but
+# such ties: one extra decimal of error in a kernel multiplies the flips by 10 and fails.
+CAP_RATE = {"vq": 3e-4, "round": 1e-5, "index": 1e-5, "argmax": 3e-4}
+
+
 def _np(t):
     return t.detach().cpu().double().numpy() if isinstance(t, torch.Tensor) else np.asarray(t, dtype=np.float64)
 
@@ -50,6 +61,15 @@ class Report:
         self.err: Dict[str, float] = {}
         self.flips: Dict[str, list] = {}
         self.notes: Dict[str, object] = {}
+        self.caps: Dict[str, list] = {}
+
+    def cap(self, name: str, kind: str, n_flips: int, n_decisions: int):
+        """Record (and enforce) the near-tie budget of one decision class of this case."""
+        import math
+        cap = max(1, int(math.ceil(CAP_RATE[kind] * n_decisions)))
+        self.caps[name] = [int(n_flips), cap, int(n_decisions)]
+        assert n_flips <= cap, (f"[{self.tag}] {name}: {n_flips} itemised near-ties in {n_decisions} decisions exceed the cap of {cap} "
+                                f"({CAP_RATE[kind]:g} per decision): an accuracy regression, not near-ties")
 
     def close(self, name: str, a, b, key: str = None):
         a, b = _np(a), _np(b)
@@ -73,7 +93,8 @@ class Report:
             os.makedirs(out, exist_ok=True)
             path = os.path.join(out, "parity_report.json")
             prev = json.load(open(path)) if os.path.exists(path) else {}
-            prev[self.tag] = {"err": self.err, "flips": {k: v[:20] for k, v in self.flips.items()}, "n_flips": self.n_flips(), "notes": self.notes}
+            prev[self.tag] = {"err": self.err, "flips": {k: v[:20] for k, v in self.flips.items()}, "n_flips": self.n_flips(), "notes": self.notes,
+                              "near_ties[count, cap, decisions]": self.caps}
             json.dump(prev, open(path, "w"), indent=1, sort_keys=True)
         except OSError:
             pass
@@ -90,6 +111,7 @@ def vq_flips(rep: Report, name: str, idx_g, idx_o, z_o, z_g, codebook):
     expanded-form distance, ~2^-22 * (|z|^2 + |e|^2))."""
     ig, io = idx_g.cpu().numpy().reshape(-1), idx_o.cpu().numpy().reshape(-1)
     mism = np.nonzero(ig != io)[0]
+    rep.cap(name, "vq", mism.size, ig.size)
     if mism.size == 0:
         return
     E = codebook.detach().cpu().double().numpy()
@@ -110,6 +132,7 @@ def round_flips(rep: Report, name: str, sym_g, sym_o, v_o, dv):
     measured at that element (+ 1 ulp of v)."""
     sg, so = sym_g.cpu().numpy().reshape(-1), sym_o.cpu().numpy().reshape(-1)
     mism = np.nonzero(sg != so)[0]
+    rep.cap(name, "round", mism.size, sg.size)
     if mism.size == 0:
         return
     v = _np(v_o).reshape(-1)
@@ -129,6 +152,7 @@ def index_flips(rep: Report, name: str, idx_g, idx_o, sigma_o, sigma_g, table):
     (+ 1 ulp) of a table entry."""
     ig, io = idx_g.cpu().numpy().reshape(-1), idx_o.cpu().numpy().reshape(-1)
     mism = np.nonzero(ig != io)[0]
+    rep.cap(name, "index", mism.size, ig.size)
     if mism.size == 0:
         return
     so = np.maximum(_np(sigma_o).reshape(-1), 0.11)
@@ -150,6 +174,7 @@ def argmax_flips(rep: Report, name: str, idx_g, logits_g, logits_o):
     io = logits_o.argmax(1)
     ig = idx_g.cpu()
     mism = (ig != io).nonzero()
+    rep.cap(name, "argmax", int(mism.shape[0]), int(ig.numel()))
     items = []
     lo, lg = logits_o.double(), logits_g.cpu().double()
     for n, y, x in mism.tolist():
@@ -318,10 +343,21 @@ def decode_parity(model, oracle, ro: Dict, q: int, rep: Report, do=None) -> Dict
     # a10/a12: the oracle's y stream through the product's entropy decoder.  Decoding is sequential: one flipped cdf
     # index desynchronises the rest, so symbols are asserted exact when the teacher-forced encode stages found no
     # index near-tie for this image (rep.flips), and the flip is reported otherwise.
-    y_hat_g, _ = model._decompress_entropy([ro["string_list"][1]], [ro["string_list"][2]], zH, zW)
     sym_ok = "y_indexes(teacher-forced)" not in rep.flips
     if sym_ok:
+        y_hat_g, _ = model._decompress_entropy([ro["string_list"][1]], [ro["string_list"][2]], zH, zW)
         rep.close("y_hat(decoded oracle stream)", y_hat_g, ro["y_hat"], key="y_hat")
+    else:
+        # an itemised (bounded, capped) cdf-index near-tie: from that symbol on the two coders disagree about the table, the rANS
+        # state desynchronises and the decoder may run off the end of the stream -- the product must then FAIL LOUDLY or return
+        # garbage of the right shape, never crash; which of the two is data dependent
+        from dc_vic_amd._lib import DcvicError
+        try:
+            y_hat_g, _ = model._decompress_entropy([ro["string_list"][1]], [ro["string_list"][2]], zH, zW)
+            assert tuple(y_hat_g.shape) == tuple(ro["y_hat"].shape)
+            rep.notes["oracle_stream_desync"] = "decoded to different symbols"
+        except DcvicError as e:
+            rep.notes["oracle_stream_desync"] = f"decoder reported: {e}"
     rep.notes["oracle_stream_decodes"] = bool(sym_ok)
     assert max(H, W) <= 1024, "tiled images are compared window by window (test_tiling_vs_oracle)"
     if do is None:
@@ -349,10 +385,74 @@ def decode_parity(model, oracle, ro: Dict, q: int, rep: Report, do=None) -> Dict
     img = model.fusion_module(dev(do["lat"]), cf, model.vq_model.decoder, w=1.0)
     rep.close("img(teacher-forced)", img, do["img"], key="img")
     # free-running decode of the oracle's y_hat
-    img_f, idx_f = model._decode(yh, 1.0, b1, b2)
+    img_f, idx_f, lg_f = model._decode(yh, 1.0, b1, b2, want_logits=True)
+    rep.close("logits(free-running decode)", lg_f, do["logits"], key="logits")
+    # every free-running argmax that differs from the oracle's must be a near-tie under the logit difference measured AT
+    # that position (and the count is capped) -- no averaged fallback
+    argmax_flips(rep, "out_idx(free-running decode)", idx_f, lg_f, do["logits"])
     if torch.equal(idx_f.cpu(), do["out_idx"]):
         rep.close("img(free-running decode)", img_f, do["img"], key="img")
     else:
-        assert "out_idx(teacher-forced feat)" in rep.flips or float((idx_f.cpu() != do["out_idx"]).float().mean()) < 2e-3
         rep.notes["free_running_argmax_flips"] = int((idx_f.cpu() != do["out_idx"]).sum())
     return dict(img=img_f, out_idx=idx_f, oracle=do)
+
+
+# ------------------------------------------------------------------------------------------- batched forward (a19)
+@torch.no_grad()
+def run_model_parity(model, ro: Dict, x: torch.Tensor, b1: float, b2: float, rep: Report) -> Dict:
+    """model.run_model(is_train=False) (hyperprior_dc_vic_model.py:112-118, 208-274) against Oracle.run_model (with its
+    intermediates) on a batch.  Integer decisions are walked in pipeline order; each class must equal the oracle's or be an
+    itemised, bounded, CAPPED near-tie -- there is no rate-only fallback:
+      VQ index   : free-running vs oracle, bound from the measured z_e difference; when one flipped, the rest of the comparison
+                   is teacher-forced through the API's own `vq_indices=` argument (the flip re-routes everything after it);
+      z symbols  : exact or rounding near-ties under the measured z difference;
+      y symbols  : the first CHARM slice that differs still has the oracle's support: rounding near-ties under the measured
+                   (y - mu) difference; later slices are legitimately re-routed;
+      argmax     : logits within TOL, flips bounded by the logit difference at that position.
+    bpp / qbpp to 4 decimals and fake_images within TOL["img"] whenever the decisions feeding them equal the oracle's."""
+    cb = model.vq_model.quantize.embedding.weight
+    xp = model.img_preprocess(x, is_train=False)
+    z_e = model.vq_model.encode(xp)
+    rep.close("z_e", z_e, ro["z_e"])
+    _, idx_f = model.vq_encode(xp, None)
+    vq_flips(rep, "vq_idx(free-running)", idx_f, ro["gt_vq_indices"], ro["z_e"], z_e, cb)
+    forced = not torch.equal(idx_f.cpu(), ro["gt_vq_indices"])
+    kw = dict(vq_indices=ro["gt_vq_indices"]) if forced else {}
+    rg = model.run_model(x, is_train=False, beta_rate=b1, beta_vq=b2, **kw)
+    assert torch.equal(rg["gt_vq_indices"].cpu(), ro["gt_vq_indices"])
+    rep.notes["run_model"] = dict(vq_teacher_forced=bool(forced))
+    # the same stages run_model took (deterministic kernels: identical values), to measure the per-element differences
+    lat, idx, feat = model.vq_encode(xp, ro["gt_vq_indices"].to(xp.device) if forced else None, want_feat=True)
+    y = model.comp_encode(xp, lat, idx, enc_kwargs=dict(beta_1=b1, beta_2=b2), feat=feat)
+    rep.close("y", y, ro["y"])
+    e = model._entropy_encode_side(y, want_symbols=True)
+    assert torch.equal(e["y_hat"], rg["y_hat"]) and torch.equal(e["z_hat"], rg["z_hat"]), "run_model is not the sum of its stages"
+    rep.close("z", e["z"], ro["z"])
+    med = model.entropy_model_z.quantiles.detach()[:, 0, 1].view(1, -1, 1, 1).cpu()
+    round_flips(rep, "z_symbols", e["z_symbols"], ro["z_symbols"], ro["z"] - med, _np(e["z"]) - _np(ro["z"]))
+    ints_ok = torch.equal(e["z_symbols"].cpu(), ro["z_symbols"])
+    if ints_ok:
+        sc = model.context_model.slice_ch
+        for i in range(model.context_model.num_slices):
+            sl = slice(i * sc, (i + 1) * sc)
+            if torch.equal(e["symbols"][:, sl].cpu(), ro["y_symbols"][:, sl]):
+                continue
+            ints_ok = False
+            dv = (_np(y[:, sl]) - _np(e["mu"][:, sl])) - (_np(ro["y"][:, sl]) - _np(ro["mu"][:, sl]))
+            round_flips(rep, f"y_symbols(slice {i})", e["symbols"][:, sl], ro["y_symbols"][:, sl], ro["y"][:, sl] - ro["mu"][:, sl], dv)
+            break
+    rep.notes["run_model"]["symbols_equal"] = bool(ints_ok)
+    if not ints_ok:
+        return rg                       # itemised + capped above; what follows a flipped symbol is re-routed
+    rep.close("mu", e["mu"], ro["mu"]); rep.close("sigma", e["sigma"], ro["sigma"])
+    rep.close("y_hat", rg["y_hat"], ro["y_hat"])
+    assert torch.equal(rg["z_hat"].cpu(), ro["z_hat"])
+    assert abs(rg["bpp"] - ro["bpp"]) < 5e-5, (rg["bpp"], ro["bpp"])
+    assert abs(rg["qbpp"] - ro["qbpp"]) < 5e-5
+    rep.notes["run_model"]["bpp"] = [rg["bpp"], ro["bpp"]]
+    rep.close("logits", rg["out_vq_logits"], ro["out_vq_logits"])
+    argmax_flips(rep, "out_idx", rg["out_vq_indices"], rg["out_vq_logits"], ro["out_vq_logits"])
+    if torch.equal(rg["out_vq_indices"].cpu(), ro["out_vq_indices"]):
+        rep.close("fake_images", rg["fake_images"], ro["fake_images"], key="img")
+        assert abs(rg["vq_accuracy"] - ro["vq_accuracy"]) < 1e-6
+    return rg

@@ -66,8 +66,14 @@ def test_stage_vq_indices(model, golden):
     zq, _, (_, _, idx) = model.vq_model.quantize(dev(golden["a4_z"]))
     assert np.array_equal(idx.cpu().numpy(), golden["a5_idx"])          # same z_e in -> index-exact
     assert np.array_equal(zq.cpu().numpy(), golden["a5_zq"])
+    # a5b: a dense random cloud around the codebook (many near-equidistant codes).  Identical z in -> every disagreement must be
+    # a tie within the fp32 slack of the expanded-form distance itself (vq_flips with dz = 0), itemised and capped
+    from parity_util import Report, vq_flips
     zq, _, (_, _, idx) = model.vq_model.quantize(dev(golden["a5b_z"]))
-    assert (idx.cpu().numpy() == golden["a5b_idx"]).mean() >= 0.999
+    rep = Report("stage_a5b_vq")
+    zb = torch.from_numpy(golden["a5b_z"])
+    vq_flips(rep, "vq_idx(a5b cloud)", idx, torch.from_numpy(golden["a5b_idx"]), zb, zb, model.vq_model.quantize.embedding.weight)
+    rep.dump()
     ok = idx.cpu().numpy() == golden["a5b_idx"]
     assert np.array_equal(zq.cpu().numpy().transpose(0, 2, 3, 1)[ok], golden["a5b_zq"].transpose(0, 2, 3, 1)[ok])
 
@@ -203,38 +209,29 @@ def test_parity_256(model, oracle, oracle_compress, seed, q):
     full_parity(model, oracle, oracle_compress, f"256_s{seed}_q{q}", ("rand", (1, 3, 256, 256), seed), img((1, 3, 256, 256), seed), q)
 
 
-@pytest.mark.parametrize("name,q", [("kodim03.png", 0), ("kodim15.png", 2), ("kodim23.png", 4)])
+@pytest.mark.parametrize("name", ["kodim03.png", "kodim15.png", "kodim23.png"])
+@pytest.mark.parametrize("q", [0, 2, 4])
 def test_parity_kodak(model, oracle, oracle_compress, name, q):
-    """BASELINE config 3: real Kodak images (the reference's demo_images, 768x512; data fixtures under tests/golden/),
-    q in {0, 2, 4}: real-bytes and predicted bpp to 4 decimals, reconstruction <= 1e-3."""
+    """BASELINE config 3: real Kodak images (the reference's demo_images, 768x512; data fixtures under tests/golden/), EVERY
+    image at EVERY q in {0, 2, 4} (the three of the 24 the reference ships x the three qualities of rd_results/kodak.csv:7,9,11):
+    real-bytes and predicted bpp to 4 decimals, reconstruction <= 1e-3."""
     x = _demo(name)
     assert x.shape == (1, 3, 512, 768)
     full_parity(model, oracle, oracle_compress, f"kodak_{name[:-4]}_q{q}", ("demo", name), x, q)
 
 
 def test_run_model_vs_oracle(model, oracle):
-    """Batched rate-estimation forward (hyperprior_dc_vic_model.py:112-118): bpp to 4 decimals and fake_images <= 1e-3 when
-    every integer decision of the batch equals the oracle's; teacher-forced through `vq_indices=` otherwise."""
-    from parity_util import TOL
+    """Batched rate-estimation forward (hyperprior_dc_vic_model.py:112-118) on a batch of two 256x256 images: stage by stage
+    against the oracle's run_model with per-element near-tie bounds and caps (parity_util.run_model_parity) -- bpp / qbpp to 4
+    decimals, fake_images <= TOL["img"], no rate-only fallback."""
+    from parity_util import Report, run_model_parity
     x = img((2, 3, 256, 256), 103)
     ro = oracle.run_model(x, 1.51, 2.25)
-    rg = model.run_model(x, is_train=False, beta_rate=1.51, beta_vq=2.25)
-    if not torch.equal(rg["gt_vq_indices"].cpu(), ro["gt_vq_indices"]):
-        assert (rg["gt_vq_indices"].cpu() != ro["gt_vq_indices"]).float().mean() < 2e-3       # itemised by test_parity_256's VQ stage
-        rg = model.run_model(x, is_train=False, beta_rate=1.51, beta_vq=2.25, vq_indices=ro["gt_vq_indices"])
-    close(rg["y_hat"], ro["y_hat"], rtol=0, atol=1.0 + 1e-3)          # a rounding near-tie moves one element by 1
-    n_sym_flip = int(((rg["y_hat"].cpu() - ro["y_hat"]).abs() > 0.5).sum())
-    if n_sym_flip == 0:
-        close(rg["y_hat"], ro["y_hat"], rtol=0, atol=TOL["y_hat"][1])
-        assert abs(rg["bpp"] - ro["bpp"]) < 5e-5, (rg["bpp"], ro["bpp"])
-        assert abs(rg["qbpp"] - ro["qbpp"]) < 5e-5
-        if torch.equal(rg["out_vq_indices"].cpu(), ro["out_vq_indices"]):
-            close(rg["fake_images"], ro["fake_images"], rtol=0, atol=TOL["img"][1])
-            assert abs(rg["vq_accuracy"] - ro["vq_accuracy"]) < 1e-6
-        else:
-            assert (rg["out_vq_indices"].cpu() != ro["out_vq_indices"]).float().mean() < 2e-3
-    else:
-        assert n_sym_flip <= 2 and abs(rg["bpp"] - ro["bpp"]) < 0.01 * ro["bpp"]
+    rep = Report("run_model_2x256")
+    try:
+        rg = run_model_parity(model, ro, x, 1.51, 2.25, rep)
+    finally:
+        rep.dump()
     close(rg["real_images"], ro["real_images"], rtol=0, atol=0)
 
 
@@ -274,6 +271,7 @@ def test_tiling_vs_oracle(model, oracle, oracle_compress):
                 _window_decode_parity(model, do, yh, b1, b2, wrep)
                 rep.flips.update({f"win({y0},{x0}) {k}": v for k, v in wrep.flips.items()})
                 rep.err.update({f"win({y0},{x0}) {k}": v for k, v in wrep.err.items()})
+                rep.caps.update({f"win({y0},{x0}) {k}": v for k, v in wrep.caps.items()})
                 off = 8 * 16
                 _x0, _y0 = x0 * 16, y0 * 16
                 l = _x0 + off if x0 > 0 else 0
@@ -281,8 +279,21 @@ def test_tiling_vs_oracle(model, oracle, oracle_compress):
                 r = _x0 + off + 256 if x0 < lefts[-1] else yW * 16
                 b = _y0 + off + 256 if y0 < tops[-1] else yH * 16
                 stitched[:, :, t:b, l:r] = o.cpu()[:, :, t - _y0:b - _y0, l - _x0:r - _x0]
+        # decode_split decodes the 8 windows as ONE batch (comp_model.TILE_BATCH); `stitched` was built window by window at N = 1
         out = model.decode_split(pdev(y_hat), 1.0, beta_rate=b1, beta_vq=b2)
-        assert torch.equal(out.cpu(), stitched), "decode_split stitching differs from the reference loop's rectangles"
+        assert torch.equal(out.cpu(), stitched), "decode_split (batched windows) differs from the reference loop's window-by-window rectangles"
+        # same for the encoder side: batched windows == one window per launch, bit for bit
+        from dc_vic_amd import comp_model as cm
+        xp = model.img_preprocess(x, is_train=False)
+        z_b = model._vq_encode_split(xp)
+        old = cm.TILE_BATCH
+        cm.TILE_BATCH = 1
+        try:
+            z_1 = model._vq_encode_split(xp)
+            out_1 = model.decode_split(pdev(y_hat), 1.0, beta_rate=b1, beta_vq=b2)
+        finally:
+            cm.TILE_BATCH = old
+        assert torch.equal(z_b, z_1) and torch.equal(out_1, out), "tiling windows as a batch change bits"
         assert float(out.min()) > -99.0                                   # every pixel was written
         # the product's own stream round-trips through the tiled decoder
         img_g, zh_g, yh_g = model.decompress(rg["string_list"])

@@ -282,6 +282,61 @@ def _disc(seed=5):
     return D
 
 
+def test_discriminator_and_losses_vs_reference_modules(train_golden):
+    """the a20 pieces the reference lets us import, pinned.  tests/golden/train.npz holds the outputs of the
+    reference's OWN DualBetaCondTamingNLayerDiscriminator (dual_beta_taming_nlayer_discriminator.py:16-89, kwargs of
+    config/exp1_stage1_3.yaml:28-41) and of its VanillaGANLoss / MSELoss / VanillaMSELoss / CrossEntropyLoss modules with the
+    YAML's kwargs.  Product side: dc_vic_amd.train.nets + the loss kernels, through the same calls the trainer makes
+    (calc_g_loss / run_discriminator / calc_d_loss, dual_cond_gan_distortion_vq_code_trainer.py:192-300): logits, loss values,
+    d(adv)/d(fake image) through the HIP data-gradient convs, d(ce)/d(logits)."""
+    import json
+    from conftest import train_golden_disc_state
+    from dc_vic_amd.train import DualBetaCondTamingNLayerDiscriminator, nets
+    from dc_vic_amd.train import autograd as A
+    from dc_vic_amd.train.trainer import DEFAULT_LOSS
+    G = train_golden
+    kw = json.loads(str(G["d_kwargs"]))
+    D = DualBetaCondTamingNLayerDiscriminator(**kw)             # the YAML's kwargs, unchanged
+    sd = train_golden_disc_state(G)
+    assert {k: tuple(v.shape) for k, v in D.state_dict().items()} == {k: tuple(v.shape) for k, v in sd.items()}      # same keys and shapes as the reference module
+    D.load_state_dict(sd, strict=True)
+    D = D.to(DEV)
+    lk = json.loads(str(G["loss_kwargs"]))
+    assert {"distortion": lk["distortion_loss"]["loss_weight"], "perceptual": lk["perceptual_loss"]["loss_weight"], "gan": lk["gan_loss"]["loss_weight"],
+            "code_distortion": lk["code_distortion_loss"]["loss_weight"], "code_ce": lk["code_ce_loss"]["loss_weight"]} == DEFAULT_LOSS
+    t = lambda k: torch.from_numpy(np.asarray(G[k])).to(DEV)
+    real, fake, b1, b2 = t("real"), t("fake"), torch.from_numpy(G["beta_1"]), torch.from_numpy(G["beta_2"])
+    grp = A.ParamGroup([D], DEV)
+    # generator side: adv = gan_loss(D(fake), is_real=True, is_disc=False), gradient back to the image
+    ctx = A.Ctx([])
+    fv = A.Var(fake)
+    g_fake = nets.discriminator_forward(ctx, D, fv, b1, b2)
+    relclose(g_fake.data, G["d_fake_logits"], 2e-5, "D(fake) logits")
+    adv = A.bce_logits_loss(ctx, g_fake, True, DEFAULT_LOSS["gan"])
+    relclose(adv, np.asarray(G["adv_loss"]).reshape(1), 2e-5, "adv loss")
+    ctx.backward()
+    relclose(fv.grad, G["adv_grad_fake"], 2e-4, "d(adv)/d(fake)")
+    # discriminator side: 0.5 * BCE(D(real), 1) + 0.5 * BCE(D(fake.detach()), 0)
+    dctx = A.Ctx([grp])
+    d_real = nets.discriminator_forward(dctx, D, A.const(real), b1, b2)
+    d_fake = nets.discriminator_forward(dctx, D, A.const(fake), b1, b2)
+    relclose(d_real.data, G["d_real_logits"], 2e-5, "D(real) logits")
+    relclose(A.bce_logits_loss(dctx, d_real, True, 0.5), np.asarray(G["d_loss_real"]).reshape(1), 2e-5, "d_real loss")
+    relclose(A.bce_logits_loss(dctx, d_fake, False, 0.5), np.asarray(G["d_loss_fake"]).reshape(1), 2e-5, "d_fake loss")
+    dctx.tape = []
+    # scalar betas
+    ds = nets.discriminator_forward(A.Ctx([]), D, A.const(real), 1.51, 2.25)
+    relclose(ds.data, G["d_real_logits_scalar_beta"], 2e-5, "D(real) logits, scalar betas")
+    # image / code losses as calc_g_loss forms them (MSELoss(50, normalize_img, '0_1') = 50 * mse on [0, 1] = 50 * 0.25 * mse on [-1, 1])
+    c2 = A.Ctx([])
+    relclose(A.mse_loss(c2, A.Var(fake), real, DEFAULT_LOSS["distortion"] * 0.25), np.asarray(G["distortion_loss"]).reshape(1), 2e-5, "distortion loss")
+    relclose(A.mse_loss(c2, A.Var(t("code_b")), t("code_a"), DEFAULT_LOSS["code_distortion"]), np.asarray(G["code_distortion_loss"]).reshape(1), 2e-5,
+             "code distortion loss")
+    lv = A.Var(t("ce_logits"))
+    relclose(A.cross_entropy_loss(c2, lv, t("ce_target"), DEFAULT_LOSS["code_ce"]), np.asarray(G["ce_loss"]).reshape(1), 2e-5, "code CE loss")
+    relclose(lv.grad, G["ce_grad"], 2e-5, "d(ce)/d(logits)")
+
+
 def test_generator_and_discriminator_step_vs_oracle(model, synth_sd):
     """One full optimisation step of the stage-3 trainer on a seeded batch (2 x 64x64, per-sample beta pairs): every loss term,
     every trainable parameter's gradient (decoder / vq_estimator / fusion_module: 33.5 M parameters), the clipped Adam update

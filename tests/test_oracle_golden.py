@@ -141,3 +141,39 @@ def test_wire_format():
     d = O.header_decode(bytes.fromhex(W["hdr_512_768_37p9_q0"]))
     assert list(d["img_size"]) == W["hdr_decode_512_768"]["img_size"]
     assert d["max_sample"] == W["hdr_decode_512_768"]["max_sample"] and d["quality_ind"] == 0
+
+
+# ------------------------------------------------------------------------------------------- a20: PatchGAN + losses (train.npz)
+def test_train_oracle_discriminator_and_losses_vs_reference_modules(train_golden):
+    """oracle/train_oracle.py against the reference's own DualBetaCondTamingNLayerDiscriminator / VanillaGANLoss / MSELoss /
+    VanillaMSELoss / CrossEntropyLoss (config/exp1_stage1_3.yaml kwargs): D logits for per-sample and scalar betas, every loss
+    value calc_g_loss / calc_d_loss forms from them, and d(adv)/d(image) through the discriminator."""
+    import torch.nn.functional as F
+    from conftest import train_golden_disc_state
+    from oracle import train_oracle as T
+    G = train_golden
+    dsd = train_golden_disc_state(G)
+    kw = json.loads(str(G["d_kwargs"]))
+    assert (kw["input_nc"], kw["n_layers"], kw["ndf"], kw["norm_type"], kw["cond_ch"], kw["L"]) == (11, 3, 64, "none", 8, 10)
+    assert (kw["max_beta_1"], kw["max_beta_2"], kw["use_pi"], kw["include_x"]) == (O.MAX_BETA_1, O.MAX_BETA_2, False, True)
+    lk = json.loads(str(G["loss_kwargs"]))
+    assert {k: v["loss_weight"] for k, v in lk.items()} == {"distortion_loss": 50, "perceptual_loss": 1.0, "gan_loss": 0.01,
+                                                            "code_distortion_loss": 1.0, "code_ce_loss": 0.5}
+    assert T.LOSS_W == dict(distortion=50.0, perceptual=1.0, gan=0.01, code_distortion=1.0, code_ce=0.5)
+    real, fake, b1, b2 = t(G["real"]), t(G["fake"]), t(G["beta_1"]), t(G["beta_2"])
+    fk = fake.clone().requires_grad_(True)
+    g_fake = T.discriminator(dsd, fk, b1, b2)
+    close(g_fake.detach(), G["d_fake_logits"], rtol=1e-5, atol=1e-6)
+    adv = T.LOSS_W["gan"] * F.binary_cross_entropy_with_logits(g_fake, torch.ones_like(g_fake))     # generator_losses' "adv" term
+    adv.backward()
+    close(adv.detach(), G["adv_loss"], rtol=1e-6, atol=0)
+    close(fk.grad, G["adv_grad_fake"], rtol=1e-4, atol=1e-9)
+    l_real, l_fake, d_real, d_fake = T.discriminator_losses(dsd, real, fake, b1, b2)
+    close(d_real.detach(), G["d_real_logits"], rtol=1e-5, atol=1e-6)
+    close(l_real.detach(), G["d_loss_real"], rtol=1e-6, atol=0)
+    close(l_fake.detach(), G["d_loss_fake"], rtol=1e-6, atol=0)
+    close(T.discriminator(dsd, real, 1.51, 2.25).detach(), G["d_real_logits_scalar_beta"], rtol=1e-5, atol=1e-6)
+    # the remaining terms exactly as generator_losses writes them
+    close(T.LOSS_W["distortion"] * F.mse_loss((real + 1.0) / 2.0, (fake + 1.0) / 2.0), G["distortion_loss"], rtol=1e-6, atol=0)
+    close(T.LOSS_W["code_distortion"] * F.mse_loss(t(G["code_a"]), t(G["code_b"])), G["code_distortion_loss"], rtol=1e-6, atol=0)
+    close(T.LOSS_W["code_ce"] * F.cross_entropy(t(G["ce_logits"]), t(G["ce_target"])), G["ce_loss"], rtol=1e-6, atol=0)
