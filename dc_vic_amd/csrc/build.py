@@ -14,7 +14,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 OUT = os.path.join(os.path.dirname(HERE), "libdcvic_hip.so")
-SOURCES = ["conv.hip", "conv3x3.hip", "wino.hip", "conv_async.hip", "conv_async16.hip", "conv1x1.hip", "gemm.hip", "attn.hip", "norm.hip", "ew.hip", "swin.hip", "vq.hip", "rate.hip", "train.hip", "error.cpp", "host_entropy.cpp"]
+SOURCES = ["conv.hip", "conv3x3.hip", "wino.hip", "wino44.hip", "conv_async.hip", "conv_async16.hip", "conv1x1.hip", "gemm.hip", "attn.hip", "norm.hip", "ew.hip", "swin.hip", "vq.hip", "rate.hip", "train.hip", "error.cpp", "host_entropy.cpp"]
 HEADERS = [os.path.join(HERE, "common.h"), os.path.join(HERE, "conv_common.h"), os.path.join(ROOT, "include", "dcvic.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wno-unused-value", "-Wno-unused-result",
          f"-I{os.path.join(ROOT, 'include')}", f"-I{HERE}"]
@@ -22,7 +22,7 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wno-unused-val
 
 # per-file extras.  wino.hip: hipcc's SLP vectoriser packs the input transform's adds into v_pk_add_f32, which costs MFMA issue
 # time beside the matrix pipe (MI355X_MICROARCH "packed f32 VALU ... an anti-lever beside MFMAs")
-EXTRA_FLAGS = {"wino.hip": ["-fno-slp-vectorize"]}
+EXTRA_FLAGS = {"wino.hip": ["-fno-slp-vectorize"], "wino44.hip": ["-fno-slp-vectorize"]}
 
 
 def _hipcc() -> str:

@@ -68,6 +68,8 @@ def conv_kernel_name(variant: int) -> str:
         return "void conv3x3_wino_kernel<0>(ConvKArgs)"
     if variant == 9101:
         return "conv3x3_wino_ups_kernel(ConvKArgs)"
+    if variant == 9104:
+        return "conv3x3_wino44_kernel(ConvKArgs)"
     if 7000 <= variant < 8000:                       # conv1x1.hip: 7000 + cls
         return f"void conv1x1_dma_kernel<{(128, 64, 32, 96)[variant - 7000]}>(ConvKArgs)"
     if 8500 <= variant < 9000:                       # conv_async16.hip: 8500 + cls*100 + P/32 (tiles in units of 16)
@@ -129,6 +131,8 @@ def shape_stats_report() -> str:
 # ------------------------------------------------------------------------------------------- conv
 # Winograd F(2x2,3x3) for the layers that opted in (ConvPlan.wino): DCVIC_WINO=0 keeps every layer on the direct kernels
 WINO_ENABLED = os.environ.get("DCVIC_WINO", "1") != "0"
+WINO44_MIN_BLOCKS = int(os.environ.get("DCVIC_WINO44_MIN_BLOCKS", "8"))   # workgroup tiles PER IMAGE below which F(2x2) / direct run
+WINO44_ENABLED = os.environ.get("DCVIC_WINO44", "1") != "0"   # F(4x4,3x3) for the layers that opted in (ConvPlan.wino44)
 WINO_MIN_BLOCKS = int(os.environ.get("DCVIC_WINO_MIN_BLOCKS", "16"))   # workgroups PER IMAGE below which the direct kernels run
 
 
@@ -140,7 +144,9 @@ class ConvPlan:
     """
 
     wino = False          # set by the owner: Winograd F(2x2,3x3) allowed (no integer decision downstream of this layer)
+    wino44 = False        # set by the owner: F(4x4,3x3) allowed too -- post-argmax layers only (3x the F(2x2) rounding error)
     _wino_pack = None
+    _wino44_pack = None
     _wino_ups_pack = None
 
     def __init__(self, weight: Tensor, bias: Optional[Tensor], kind: str = "conv", stride: int = 1,
@@ -231,6 +237,19 @@ class ConvPlan:
             return False
         return ty * tx * ((self.Cout + 63) // 64) >= WINO_MIN_BLOCKS
 
+    def _wino44_ok(self, srcs, N: int, H: int, W: int) -> bool:
+        """F(4x4, 3x3) eligibility: Conv2d(k3, s1, p1), Cin % 8 == 0 with 4-channel-aligned sources, width % 4 == 0, and a map that
+        fills its 64-channel x 16 x 32-pixel workgroup tiles.  A function of the layer and the image size only, never of N."""
+        if self.kind != "conv" or self.upsample or self.ups_phases or self.stride != 1 or self.pad != (1, 1) \
+                or (self.KH, self.KW) != (3, 3) or self._w is None:
+            return False
+        if (W & 3) or self.Cout < 48 or self.Cin % 8 or any(s.shape[1] % 4 or s.data_ptr() % 16 or (s.shape[0] > 1 and s.stride(0) % 4) for s in srcs):
+            return False
+        ty, tx = (H + 15) // 16, (W + 31) // 32
+        if H * W < 0.6 * (ty * 16 * tx * 32):
+            return False
+        return ty * tx * ((self.Cout + 63) // 64) >= WINO44_MIN_BLOCKS
+
     def _wino_ups_ok(self, srcs, H: int, W: int) -> bool:
         """Eligibility of the upsample-fused Winograd (input H x W, output 2H x 2W): as _wino_ok, on the output's tile grid."""
         if (W & 3) or self.Cout < 48 or any(s.shape[1] % 8 or s.data_ptr() % 16 or (s.shape[0] > 1 and s.stride(0) % 4) for s in srcs):
@@ -307,6 +326,26 @@ class ConvPlan:
             if sc.shape[0] not in (1, N):
                 raise ValueError("conv affine batch must be 1 or N")
         st = _stream()
+        if self.wino44 and WINO44_ENABLED and self.wino and WINO_ENABLED and not self.ups_phases and not self.upsample and init is None and affine is None \
+                and act in (ACT_NONE, ACT_RELU, ACT_LRELU02) \
+                and (self.wino44 == "force" or self._wino44_ok(srcs, N, H, W)) \
+                and out.data_ptr() % 16 == 0 and _bs(out) % 4 == 0 and (res is None or (res.data_ptr() % 16 == 0 and _bs(res) % 4 == 0)):
+            if self._wino44_pack is None:
+                nbytes = lib().dcvic_wino44_packed_bytes(self.Cin, self.Cout)
+                self._wino44_pack = torch.empty(nbytes // 4, dtype=torch.float32, device=self._w.device)
+                check(lib().dcvic_wino44_pack_f32(_p(self._w), _p(self._wino44_pack), self.Cin, self.Cout, st), "wino44_pack")
+            io.Hout, io.Wout = Hf, Wf
+            io.osy = io.osx = 1
+            io.ooy = io.oox = 0
+            if _EVENTS is not None:
+                e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+                e0.record()
+                check(lib().dcvic_conv3x3_wino44_f32(self.Cin, self.Cout, _p(self._wino44_pack), C.byref(io), st), "conv3x3_wino44")
+                e1.record()
+                _EVENTS.append((9104, 2.0 * N * H * W * self.Cout * self.Cin * 9, e0, e1, (self.Cin, self.Cout, 9, 1, 0, H, W, N)))
+            else:
+                check(lib().dcvic_conv3x3_wino44_f32(self.Cin, self.Cout, _p(self._wino44_pack), C.byref(io), st), "conv3x3_wino44")
+            return out
         if self.wino and WINO_ENABLED and not self.ups_phases and not self.upsample and init is None and affine is None \
                 and (self.wino == "force" or self._wino_ok(srcs, N, H, W)) \
                 and out.data_ptr() % 16 == 0 and _bs(out) % 4 == 0 and (res is None or (res.data_ptr() % 16 == 0 and _bs(res) % 4 == 0)):

@@ -156,6 +156,18 @@ int dcvic_conv3x3_wino_f32(int Cin, int Cout, const float* packed, const dcvic_c
 size_t dcvic_wino_ups_packed_bytes(int Cin, int Cout);
 int dcvic_wino_ups_pack_f32(const float* w, float* packed, int Cin, int Cout, void* stream);
 int dcvic_conv3x3_wino_ups_f32(int Cin, int Cout, const float* packed, const dcvic_conv_io* io, void* stream);
+/* Conv2d(k3, s1, p1) as Winograd F(4x4, 3x3) on fp32 MFMA (csrc/wino44.hip): 36 multiplies per 4x4 outputs and input channel, 2.25
+ * per output (F(2x2, 3x3): 4; the direct sum: 9), interpolation points 0, +-3/4, +-3/2, inf (all transform constants dyadic).  Its
+ * rounding error is ~3x that of dcvic_conv3x3_wino_f32 (1.5e-6 rms relative per layer), so callers use it ONLY for the layers after
+ * the path's last integer decision -- the frozen VQGAN decoder and the SFT fusion blocks (same reference operators as
+ * dcvic_conv3x3_wino_f32: ldm/modules/diffusionmodules/model.py:82-141, 462-568; codeformer_layers.py:20-67;
+ * vq_fusion_module.py:78-126) -- where it moves the reconstruction at the 1e-5 level (contract: 1e-3) and cannot touch indices or
+ * bitstreams.  io contract of dcvic_conv3x3_wino_f32, with every source a multiple of 4 channels and Cin a multiple of 8.
+ * Weights: G g G^T in fp64, rounded once, packed per (64-channel tile, 4-channel chunk) as the kernel's 36 KiB LDS image.
+ * Deterministic and batch-invariant. */
+size_t dcvic_wino44_packed_bytes(int Cin, int Cout);
+int dcvic_wino44_pack_f32(const float* w, float* packed, int Cin, int Cout, void* stream);
+int dcvic_conv3x3_wino44_f32(int Cin, int Cout, const float* packed, const dcvic_conv_io* io, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Batched strided GEMM  C[b][m][n] = alpha * sum_k A[b][m][k] * B[b][k][n]

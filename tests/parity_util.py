@@ -343,7 +343,9 @@ def decode_parity(model, oracle, ro: Dict, q: int, rep: Report, do=None) -> Dict
     # a10/a12: the oracle's y stream through the product's entropy decoder.  Decoding is sequential: one flipped cdf
     # index desynchronises the rest, so symbols are asserted exact when the teacher-forced encode stages found no
     # index near-tie for this image (rep.flips), and the flip is reported otherwise.
-    sym_ok = "y_indexes(teacher-forced)" not in rep.flips
+    # (the decoder derives its cdf indexes from ITS OWN hyper-decoder output, so an index near-tie itemised by the free-running
+    # compress -- product sigma vs oracle sigma -- applies here too, not only one found under teacher forcing)
+    sym_ok = not any(k.startswith("y_indexes") for k in rep.flips)
     if sym_ok:
         y_hat_g, _ = model._decompress_entropy([ro["string_list"][1]], [ro["string_list"][2]], zH, zW)
         rep.close("y_hat(decoded oracle stream)", y_hat_g, ro["y_hat"], key="y_hat")

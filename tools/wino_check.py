@@ -6,6 +6,9 @@ import torch.nn.functional as F
 from dc_vic_amd import ops
 
 
+F44 = os.environ.get("WINO_CHECK_F44") == "1"       # the "wino" column runs F(4x4, 3x3) (csrc/wino44.hip) instead of F(2x2, 3x3)
+
+
 def run(Cin, Cout, H, W, N, reps=5, res=False, act=0, check=True, srcs_split=None):
     dev = torch.device("cuda:0")
     g = torch.Generator().manual_seed(Cin * 7 + Cout + H)
@@ -15,6 +18,8 @@ def run(Cin, Cout, H, W, N, reps=5, res=False, act=0, check=True, srcs_split=Non
     r = torch.randn((N, Cout, H, W), generator=g).to(dev) if res else None
     direct = ops.ConvPlan(w, b, "conv", pad=(1, 1))
     wino = ops.ConvPlan(w, b, "conv", pad=(1, 1)); wino.wino = "force"
+    if F44:
+        wino.wino44 = "force"
     srcs = x if srcs_split is None else list(torch.split(x, srcs_split, dim=1))
     if srcs_split is not None:
         srcs = [s.contiguous() for s in srcs]
