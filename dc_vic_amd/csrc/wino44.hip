@@ -15,22 +15,24 @@
 //                    y2 = 9/16 (m1 + m2) + 9/4 (m3 + m4)    y3 = 27/64 (m1 - m2) + 27/8 (m3 - m4) + m5
 //   G (fp64, at pack time): rows [64/81, 0, 0], [-128/243, -+32/81, -8/27] (x2), [32/243, +-16/81, 8/27] (x2), [0, 0, 1]
 //
-// One PERSISTENT workgroup per CU = 256 threads = 4 waves, ONE PER SIMD (512 registers each): a lone wave hides its side work in
-// the 24 issue cycles every `v_mfma_f32_16x16x4_f32` leaves free, where two waves per SIMD pay for it additively (the F(2x2) kernel's
-// experiments, profiles/r2_wino_experiments.md), and a stage of this kernel has 1.7x the side work per MFMA of an F(2x2) stage.
-//   * workgroup tile: 64 output channels x (16 rows x 32 columns) = 32 tiles of 4x4; a pipeline stage is FOUR input channels (one
-//     k-step of the MFMA).  Wave cg owns output channels 16 cg .. 16 cg + 15 for all 32 tiles and all 36 positions: 72 accumulators
-//     of 16x16 (288 registers), so the output transform A^T M A is register-only, exactly as in wino.hip.
-//   * per stage, by LDS-DMA (`global_load_lds_dwordx4`): the pre-transformed weights U (36 positions x 4 ch x 64 co = 36 KiB, packed
-//     as the LDS image [position group 9][cg 4][k 4][m 16][4 positions]) one stage ahead, and the raw input patch (4 ch x 18 rows x
-//     ten 16-byte segments) three stages ahead.
-//   * input transform: 128 (channel, tile) patches per stage, 256 threads -> every thread transforms ONE 6x6 patch per TWO stages,
-//     software-pipelined: wave pair g % 2 runs "half A" of stage g + 2 (18 LDS reads + the column pass, 72 fma) while the other pair
-//     runs "half B" of stage g + 1 (row pass, 72 fma + 12 stores into the V image [position group][block 2][k 4][n 16][4 positions]):
-//     the same instruction count for every wave in every stage, 1 - 2 instructions behind each MFMA.
-//   * MFMA operands: one ds_read_b128 (U: four positions) + two (V: four positions x two 16-tile blocks) per 8 MFMAs.
-// LDS: 2 x 12 KiB raw patch + 2 x 36 KiB U + 2 x 18 KiB V + two bias rows = 132.5 KiB.
-// Deterministic and batch-invariant: per position the reduction runs over the 4-channel chunks ascending inside the MFMA's ordered
+// One PERSISTENT workgroup per CU = 256 threads = 4 waves, ONE PER SIMD (512 registers each).
+//   * workgroup tile: 64 output channels x (16 rows x 32 columns) = 32 tiles of 4x4; a pipeline stage is EIGHT input channels = two
+//     k-steps of the MFMA (144 MFMAs per wave and barrier).  Wave cg owns output channels 16 cg .. 16 cg + 15 for all 32 tiles and all
+//     36 positions: 72 accumulators of 16x16 (288 registers: 256 in the accumulator file, 32 in VGPRs), so the output transform
+//     A^T M A is register-only, exactly as in wino.hip.
+//   * the pre-transformed weights U never touch LDS: no two waves of a workgroup share a co group, so each wave fetches ITS 16 co x
+//     4 ch x 36 positions of the next k-step straight into operand registers (nine `global_load_dwordx4` per k-step from the packed
+//     image [k-step 2][position group 9][cg 4][k 4][m 16][4 positions]; L2-resident: the tile order keeps an XCD on one co-tile).
+//     (First build: U through LDS by LDS-DMA like wino.hip -- 12 DMA pieces per 72 MFMAs cost 0.54 of 1.90 ms, ~105 cycles of the
+//     SIMD's issue each: profiles/r3_wino44_experiments.md.)
+//   * the raw input patch (8 ch x 18 rows x ten 16-byte segments) arrives by LDS-DMA (`global_load_lds_dwordx4`, six pieces per wave
+//     and stage) two stages ahead.
+//   * input transform: 256 (channel, tile) patches per stage = ONE 6x6 patch per thread and stage (18 LDS reads, column pass + row
+//     pass = 144 fma, 12 stores into the V image [k-step][position group][block 2][k 4][n 16][4 positions]), its instructions placed
+//     one quarter-pass (3 fma) behind every second MFMA.
+//   * MFMA operands: A (U) from registers, B (V) by two ds_read_b128 (four positions x two 16-tile blocks) per 8 MFMAs.
+// LDS: 2 x 24 KiB raw patch + 2 x 36 KiB V + two bias rows = 120.5 KiB.
+// Deterministic and batch-invariant: per position the reduction runs over the 4-channel k-steps ascending inside the MFMA's ordered
 // fmaf chain; the tiling never depends on N.
 #include "conv_common.h"
 
@@ -52,16 +54,15 @@ __device__ float dcvic_w44_zero[16];   // zero-initialised: source of padded lan
 #define F4_PW 40           // LDS row: columns ox0 - 4 .. ox0 + 35 as ten 16-byte segments; the patch's 34 columns sit at 3 .. 36
 #define F4_PROWS 18
 #define F4_PLANE 720
-#define F4_KC 4
-#define F4_SEGS 720        // float4 segments of a stage: 4 ch x 18 rows x 10
-#define F4_XSLOTS 3
-#define F4_XS 3072         // floats (768 lanes x 4: the last slot's idle lanes write zeros behind the patch)
-#define F4_US 9216         // 36 positions x 4 ch x 64 co
-#define F4_VS 4608         // 36 positions x 4 ch x 32 tiles
+#define F4_KC 8            // input channels per stage (two k-steps of four)
+#define F4_SEGS 1440       // float4 segments of a stage: 8 ch x 18 rows x 10
+#define F4_XSLOTS 6
+#define F4_XS 6144         // floats (1536 lanes x 4: the last slot's idle lanes write zeros behind the patch)
+#define F4_US 18432        // floats of a stage's packed weights: 2 k-steps x 36 positions x 4 ch x 64 co
+#define F4_VS 9216         // 2 k-steps x 36 positions x 4 ch x 32 tiles
 #define F4_CO 64
 #define F4_THREADS 256
-#define F4_OFF_U (2 * F4_XS)
-#define F4_OFF_V (F4_OFF_U + 2 * F4_US)
+#define F4_OFF_V (2 * F4_XS)
 #define F4_OFF_BIAS (F4_OFF_V + 2 * F4_VS)
 #define F4_LDS_FLOATS (F4_OFF_BIAS + 2 * F4_CO)
 
@@ -82,7 +83,7 @@ __device__ __forceinline__ double f4_u(const float* g, int a, int b) {
     return s;
 }
 
-// packed[cotile][chunk][group 9][cg 4][k 4][m 16][slot 4]  <-  w[Cout][Cin][3][3]   (fp64 transform, rounded once)
+// packed[cotile][chunk][k-step 2][group 9][cg 4][k 4][m 16][slot 4]  <-  w[Cout][Cin][3][3]   (fp64 transform, rounded once)
 __global__ void wino44_pack_kernel(const float* __restrict__ w, float* __restrict__ wp, int Cin, int Cout, int n_chunks, long long total) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= total) return;
@@ -92,12 +93,13 @@ __global__ void wino44_pack_kernel(const float* __restrict__ w, float* __restric
     const int k = r & 3; r >>= 2;
     const int cg = r & 3; r >>= 2;
     const int pg = (int)(r % 9); r /= 9;
+    const int ks = (int)(r & 1); r >>= 1;
     const int chunk = (int)(r % n_chunks);
     const int cotile = (int)(r / n_chunks);
     const int idx = pg * 4 + slot;
     int a, b;
     if (idx < 24) { a = idx >> 2; b = (idx & 3) + 1; } else { a = (idx - 24) >> 1; b = ((idx - 24) & 1) ? 5 : 0; }
-    const int co = cotile * F4_CO + cg * 16 + m, ci = chunk * F4_KC + k;
+    const int co = cotile * F4_CO + cg * 16 + m, ci = chunk * F4_KC + 4 * ks + k;
     float v = 0.f;
     if (co < Cout && ci < Cin) v = (float)f4_u(w + ((long long)co * Cin + ci) * 9, a, b);
     wp[i] = v;
@@ -141,13 +143,12 @@ __global__ __launch_bounds__(F4_THREADS, 1) void conv3x3_wino44_kernel(const Con
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // 0..3
-    const int pair = wave >> 1;
 
     const long long HW = (long long)K.H * K.W;
-    const int S = K.n_chunks;                                     // stages (4-channel chunks) per tile
+    const int S = K.n_chunks;                                     // stages (8-channel chunks) per tile
     const long long x_stride = (long long)F4_KC * HW;
 
-    // ---- PERSISTENT workgroup (as wino.hip): XCD x = blockIdx.x % 8 owns a contiguous range of tile indices, cotile fastest
+    // ---- PERSISTENT workgroup (as wino.hip): XCD x = blockIdx.x % 8 owns a contiguous range of tile indices
     int xe;
     const int J = (int)gridDim.x / NXCD;
     int first;
@@ -162,8 +163,7 @@ __global__ __launch_bounds__(F4_THREADS, 1) void conv3x3_wino44_kernel(const Con
     const int total = ntile * S;
     // tile index b = (cotile, image, tile row, tile column), cotile SLOWEST: an XCD's contiguous range then lies inside one or two
     // co-tiles, whose weight slabs (36 positions x Cin x 64 co x 4 B = 2.4 MB at Cin = 256) stay in that XCD's 4 MiB L2 for the whole
-    // launch.  (Cotile fastest, as in wino.hip, cycles ALL of U -- 9.4 MB at 256 -> 256 -- through every L2: the 36 KiB slab per stage
-    // then streams from the Infinity Cache at the ~25 GB/s per CU an LDS-DMA loader gets beyond L2, i.e. 1.4 us per 0.96-us stage.)
+    // launch, where every wave's direct weight loads find them.
     const int n_ptiles = K.nblocks / K.n_cotiles;
     auto decode = [&](int b, int& cotile, int& n, int& oy0, int& ox0) __attribute__((always_inline)) {
         cotile = b / n_ptiles; b -= cotile * n_ptiles;
@@ -173,7 +173,7 @@ __global__ __launch_bounds__(F4_THREADS, 1) void conv3x3_wino44_kernel(const Con
     };
     auto cotile_of = [&](int b) __attribute__((always_inline)) { return b / n_ptiles; };
 
-    // ---- raw-patch DMA: float4 segment e = tid + s*256 of [4 ch][18 rows][10 segments]
+    // ---- raw-patch DMA: float4 segment e = tid + s*256 of [8 ch][18 rows][10 segments]
     const float* xp[F4_XSLOTS];
     int poff[F4_XSLOTS];
     int x_left = 0, x_n = 0, x_b = first, x_next = 0;
@@ -203,23 +203,33 @@ __global__ __launch_bounds__(F4_THREADS, 1) void conv3x3_wino44_kernel(const Con
         x_rebase(0);
     };
     x_setup(first);
-    // ---- weight DMA: the stage's 36 KiB slab is already the LDS image; thread moves float4 #(tid + j*256), j = 0..8
-    const float* wp0;
-    const unsigned u_lane = 16u * (unsigned)tid;
+    // ---- weights: this wave's slice of the packed image, fetched straight into operand registers.  wp_nxt = the slab of the NEXT
+    // stage of the stream (its first k-step is loaded during the second k-step of the current stage).
+    const int cg = wave;
+    const unsigned u_voff = 16u * (unsigned)(cg * 64 + lane);     // byte offset inside a (k-step, group) block of 4 KiB
+    const float* wp_cur;
+    const float* wp_nxt;
     int u_b = first, u_next = 0;
-    auto u_setup = [&](int b) __attribute__((always_inline)) { wp0 = K.wp + (long long)cotile_of(b) * S * (long long)F4_US; };
+    auto u_setup = [&](int b) __attribute__((always_inline)) { wp_nxt = K.wp + (long long)cotile_of(b) * S * (long long)F4_US; };
     u_setup(first);
+    wp_cur = wp_nxt;
+    auto u_advance = [&]() __attribute__((always_inline)) {       // wp_nxt: on to the next stage of the stream
+        if (++u_next == S) {
+            u_next = 0;
+            u_b += J;
+            if (u_b < xe) u_setup(u_b);
+        } else {
+            wp_nxt += F4_US;
+        }
+    };
+    u_advance();
 
-    // ---- input transform: pair-local thread i = (wave & 1) * 64 + lane -> channel k = i / 32, tile t = i % 32 (block t / 16, column n = t % 16
-    //      of the MFMA's B operand); tile (row ty = t / 8, column tx = t % 8) of the 4 x 8 tile grid
-    const int t_i = (wave & 1) * 64 + lane;
-    const int t_k = t_i >> 5, t_t = t_i & 31;
+    // ---- input transform: thread -> channel k = tid / 32 (k-step k / 4), tile t = tid % 32 (block t / 16, column n = t % 16 of the
+    //      MFMA's B operand); tile (row ty = t / 8, column tx = t % 8) of the 4 x 8 tile grid
+    const int t_k = tid >> 5, t_t = tid & 31;
     const int t_blk = t_t >> 4, t_n = t_t & 15, t_ty = t_t >> 3, t_tx = t_t & 7;
     const unsigned t_src = 4u * (unsigned)(t_k * F4_PLANE + (4 * t_ty) * F4_PW + 4 * t_tx + 3);
-    const unsigned t_dst = 4u * (unsigned)(F4_OFF_V + (t_blk * 64 + t_k * 16 + t_n) * 4);
-    // ---- MFMA operands
-    const int cg = wave;
-    const unsigned op_u = 4u * (unsigned)(F4_OFF_U + (cg * 64 + lane) * 4);
+    const unsigned t_dst = 4u * (unsigned)(F4_OFF_V + (t_k >> 2) * 4608 + (t_blk * 64 + (t_k & 3) * 16 + t_n) * 4);
     const unsigned op_v = 4u * (unsigned)(F4_OFF_V + lane * 4);
 
     // 72 accumulators of 16x16 = 288 registers, but the accumulator file (AGPRs) holds 256 and hipcc (ROCm 7.2), given the builtin,
@@ -232,7 +242,7 @@ __global__ __launch_bounds__(F4_THREADS, 1) void conv3x3_wino44_kernel(const Con
     f32x4 accv[4][2];
 
     // All LDS traffic of the loop is inline asm with hand-placed waits (see wino.hip: hipcc guards every LDS access it can see with
-    // `s_waitcnt vmcnt(0)` while an LDS-DMA is in flight).
+    // `s_waitcnt vmcnt(0)` while an LDS-DMA is in flight); so are the weight loads (their landing is awaited once per k-step).
 #define F4_FENCE() __builtin_amdgcn_sched_barrier(0)
 #define F4_WAIT_LDS() do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); F4_FENCE(); } while (0)
     // the 6x6 patch of this thread, row r = (dl[r] | dm[r][0..3] | dr[r]); transformed in place; after the row pass the edge
@@ -271,28 +281,24 @@ __global__ __launch_bounds__(F4_THREADS, 1) void conv3x3_wino44_kernel(const Con
             asm volatile("ds_write_b64 %0, %1 offset:%2" :: "v"(vaddr), "v"(v), "n"((6 + a / 2) * 2048 + 8 * (a & 1)) : "memory");
         }
     };
-    f32x4 opA[3];                                                 // [set = group % 3]: four positions of this lane's (co, channel)
-    f32x4 opB[3][2];                                              // [set][block]: four positions of this lane's (channel, tile)
-    auto op_load = [&](auto g_, auto set_, unsigned ua, unsigned va) {
-        constexpr int pg = decltype(g_)::value, set = decltype(set_)::value;
-        f32x4 &a = opA[set];
+    f32x4 uA[2][9];                                               // [k-step][position group]: four positions of this lane's (co, channel)
+    f32x4 opB[3][2];                                              // [set = group % 3][block]: four positions of this lane's (channel, tile)
+    auto u_load = [&](auto ks_, auto pg_, const float* slab) {     // U of (k-step, group) of the stage whose slab is given -> uA[ks][pg]
+        constexpr int ks = decltype(ks_)::value, pg = decltype(pg_)::value;
+        f32x4& dst = uA[ks][pg];
+        const float* base = slab + (ks * 9 + pg) * 1024;          // (uniform: scalar base + 32-bit lane offset, the saddr form)
+        const unsigned vo = u_voff;                               // (asm operands inside a generic lambda do not capture)
+        asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(dst) : "v"(vo), "s"(base) : "memory");
+    };
+    auto op_load = [&](auto G_, unsigned va) {                    // B operands of group G = 9 ks + pg of a stage
+        constexpr int G = decltype(G_)::value, set = G % 3, ks = G / 9, pg = G % 9;
         f32x4 &b0 = opB[set][0], &b1 = opB[set][1];
-        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(a) : "v"(ua), "n"(4096 * pg));
-        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(b0) : "v"(va), "n"(1024 * (2 * pg)));
-        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(b1) : "v"(va), "n"(1024 * (2 * pg + 1)));
+        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(b0) : "v"(va), "n"(ks * 18432 + 1024 * (2 * pg)));
+        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(b1) : "v"(va), "n"(ks * 18432 + 1024 * (2 * pg + 1)));
     };
     auto dma_x = [&](auto s_, int buf) {
         constexpr int sl = decltype(s_)::value;
         __builtin_amdgcn_global_load_lds(reinterpret_cast<const float4*>(xp[sl]), (lds_ptr_t)(smem + buf * F4_XS + (wave * 64 + sl * F4_THREADS) * 4), 16, 0, 0);
-    };
-    auto dma_u = [&](auto j_, int buf) {
-        constexpr int j = decltype(j_)::value;
-        // saddr form by hand: scalar base + 32-bit lane offset (see wino.hip)
-        const unsigned voff = u_lane + 16u * F4_THREADS * j;
-        const unsigned long long sb = (unsigned long long)__builtin_amdgcn_readfirstlane((int)(reinterpret_cast<unsigned long long>(wp0) & 0xffffffffull)) & 0xffffffffull
-                                    | ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(reinterpret_cast<unsigned long long>(wp0) >> 32)) << 32);
-        const unsigned lds = (unsigned)(4 * (F4_OFF_U + buf * F4_US + (wave * 64 + j * F4_THREADS) * 4));
-        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" :: "v"(voff), "s"(sb), "s"(lds) : "memory", "m0");
     };
     auto x_advance = [&]() __attribute__((always_inline)) {
         if (++x_next == S) {
@@ -309,15 +315,6 @@ __global__ __launch_bounds__(F4_THREADS, 1) void conv3x3_wino44_kernel(const Con
             }
         }
     };
-    auto u_advance = [&]() __attribute__((always_inline)) {
-        if (++u_next == S) {
-            u_next = 0;
-            u_b += J;
-            if (u_b < xe) u_setup(u_b);
-        } else {
-            wp0 += F4_US;
-        }
-    };
 
     // ---- epilogue of one tile, in registers: lane holds element (co = 16 cg + 4 (lane / 16) + r, tile = 16 blk + lane % 16) of all 36
     // positions.  A^T M A per (block, r): 6 column passes + 4 row passes, bias -> act -> (+ res) -> four 16-byte row stores.
@@ -326,7 +323,7 @@ __global__ __launch_bounds__(F4_THREADS, 1) void conv3x3_wino44_kernel(const Con
     const float neg_slope = K.act == DCVIC_ACT_RELU ? 0.f : K.act == DCVIC_ACT_LRELU02 ? 0.2f : 1.f;
     const bool has_bias = K.bias != nullptr, has_res = K.res != nullptr;
     auto tile_epilogue = [&](int cotile, int n, int oy0, int ox0, int par) __attribute__((always_inline)) {
-        asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");          // the inline-asm MFMAs' results (accv) are read below
+        asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");          // the inline-asm MFMAs' results are read below
         auto A = [&](auto idx_, auto blk_, int r) __attribute__((always_inline)) -> float {
             constexpr int idx = decltype(idx_)::value, blk = decltype(blk_)::value;
             if constexpr (idx < 32) {
@@ -399,111 +396,98 @@ __global__ __launch_bounds__(F4_THREADS, 1) void conv3x3_wino44_kernel(const Con
     };
 
     // ---- pipeline
-    int c_b = first, c_par = 0;                      // compute stream: tile, chunk inside it, tile parity
+    int c_b = first, c_par = 0;                                   // compute stream: tile, tile parity
     int c_cotile, c_n, c_oy0, c_ox0;
     decode(first, c_cotile, c_n, c_oy0, c_ox0);
     stage_bias(first, 0);
-    // prologue: X(0) -> Xr[0], X(1) -> Xr[1], U(0) -> U[0]; pair 0 transforms stage 0 completely, pair 1 runs half A of stage 1;
-    // then X(2) -> Xr[0]
+    // prologue: X(0) -> Xr[0], X(1) -> Xr[1], U(stage 0, k-step 0) -> uA[0]; every thread transforms its patch of stage 0 -> V[0]
     dcvic_static_for<0, F4_XSLOTS>([&](auto s_) { dma_x(s_, 0); });
     x_advance();
     if (total > 1) {
         dcvic_static_for<0, F4_XSLOTS>([&](auto s_) { dma_x(s_, 1); });
         x_advance();
     }
-    dcvic_static_for<0, 9>([&](auto j_) { dma_u(j_, 0); });
-    u_advance();
+    dcvic_static_for<0, 9>([&](auto pg_) { u_load(std::integral_constant<int, 0>{}, pg_, wp_cur); });
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     F4_FENCE();
-    if (pair == 0 || total > 1) {
-        const unsigned xa = t_src + (unsigned)(pair * F4_XS * 4);
-        dcvic_static_for<0, 6>([&](auto r_) { t_load(r_, xa); });
-        F4_WAIT_LDS();
-        dcvic_static_for<0, 6>([&](auto c_) { dcvic_static_for<0, 4>([&](auto q_) { t_col(c_, q_); }); });
-        if (pair == 0) {
-            dcvic_static_for<0, 6>([&](auto a_) { dcvic_static_for<0, 4>([&](auto q_) { t_row(a_, q_); }); });
-            dcvic_static_for<0, 12>([&](auto i_) { t_store(i_, t_dst); });
-        }
-    }
+    dcvic_static_for<0, 6>([&](auto r_) { t_load(r_, t_src); });
+    F4_WAIT_LDS();
+    dcvic_static_for<0, 6>([&](auto c_) { dcvic_static_for<0, 4>([&](auto q_) { t_col(c_, q_); }); });
+    dcvic_static_for<0, 6>([&](auto a_) { dcvic_static_for<0, 4>([&](auto q_) { t_row(a_, q_); }); });
+    dcvic_static_for<0, 12>([&](auto i_) { t_store(i_, t_dst); });
     F4_WAIT_LDS();
     __syncthreads();
     F4_FENCE();
-    if (total > 2) {
-        dcvic_static_for<0, F4_XSLOTS>([&](auto s_) { dma_x(s_, 0); });
-        x_advance();
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
-    __syncthreads();
-    F4_FENCE();
-    op_load(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, op_u, op_v);
+    op_load(std::integral_constant<int, 0>{}, op_v);
 
-    // ROLE 0: half A of stage g + 2; ROLE 1: half B of stage g + 1.  The body has NO run-time condition: past the end of the stream the
-    // DMA simply re-fetches the last slab / patch (the advance functions stop), the transform halves work on stale LDS data and write
-    // a V image nobody reads.  A stage has NINE operand groups, read through THREE register sets (group pg -> set pg % 3), so that
-    // group 8 (set 2) and the next stage's group 0 (set 0, requested behind the barrier) never share one.
-    auto run_stage = [&](auto role_, int g) __attribute__((always_inline)) {
-        constexpr int ROLE = decltype(role_)::value;
-        const int cur = g & 1, nxt = cur ^ 1;
-        const unsigned ua = op_u + (unsigned)(cur * F4_US * 4), va = op_v + (unsigned)(cur * F4_VS * 4);
-        const unsigned xaddr = t_src + (unsigned)(cur * F4_XS * 4);       // X(g + 2) lives in Xr[g & 1]
-        const unsigned vaddr = t_dst + (unsigned)(nxt * F4_VS * 4);       // V(g + 1)
-        // 72 MFMA slots = 9 position groups x (4 positions x 2 blocks).  In front of a group's eight MFMAs: wait for its operands, then
-        // request the next group's.  The stage BARRIER sits in front of the LAST group (every LDS read of this stage has returned, the
-        // transform's stores and this wave's DMA pieces have landed); behind it the first operands of stage g + 1 are requested.
-        dcvic_static_for<0, 9>([&](auto pg_) {
-            constexpr int pg = decltype(pg_)::value, set = pg % 3;
-            if constexpr (pg < 8) {
+    // One stage = 18 operand groups G = 9 ks + pg (k-step, position group) x 8 MFMAs (4 positions x 2 blocks) = 144 slots.  The body has
+    // NO run-time condition: past the end of the stream the loads simply re-fetch the last slab / patch (the advance functions stop),
+    // the transform works on stale LDS data and writes a V image nobody reads.
+    //   in front of a group's MFMAs: wait for its B operands (lgkmcnt), request the next group's; group 9 (the second k-step) also waits
+    //   for the weights loaded during the first (vmcnt);
+    //   the stage BARRIER sits in front of the LAST group: every LDS read of this stage has returned, the transform's stores, this wave's
+    //   DMA pieces and the next stage's first weights have landed; behind it the first B operands of stage s + 1 are requested;
+    //   B operands rotate through THREE register sets (group G -> set G % 3: group 17 and the next stage's group 0 never share one).
+    auto run_stage = [&](int s) __attribute__((always_inline)) {
+        const int cur = s & 1, nxt = cur ^ 1;
+        const unsigned va = op_v + (unsigned)(cur * F4_VS * 4);
+        const unsigned xaddr = t_src + (unsigned)(nxt * F4_XS * 4);      // X(s + 1) lives in Xr[(s + 1) & 1]
+        const unsigned vaddr = t_dst + (unsigned)(nxt * F4_VS * 4);      // V(s + 1)
+        dcvic_static_for<0, 18>([&](auto G_) {
+            constexpr int G = decltype(G_)::value, ks = G / 9, pg = G % 9, set = G % 3;
+            if constexpr (G < 17) {
                 if constexpr (!(DCVIC_W44_DBG & 8)) {
-                    F4_WAIT_LDS();
-                    op_load(std::integral_constant<int, pg + 1>{}, std::integral_constant<int, (pg + 1) % 3>{}, ua, va);
+                    if constexpr (G == 9) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+                    else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    F4_FENCE();
+                    op_load(std::integral_constant<int, G + 1>{}, va);
                 }
             } else {
                 if constexpr (DCVIC_W44_DBG & 64) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
                 if constexpr (!(DCVIC_W44_DBG & 1)) __syncthreads();
                 F4_FENCE();
-                if constexpr (!(DCVIC_W44_DBG & 8))
-                    op_load(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, op_u + (unsigned)(nxt * F4_US * 4), op_v + (unsigned)(nxt * F4_VS * 4));
+                if constexpr (!(DCVIC_W44_DBG & 8)) op_load(std::integral_constant<int, 0>{}, op_v + (unsigned)(nxt * F4_VS * 4));
             }
             F4_FENCE();
             dcvic_static_for<0, 8>([&](auto q_) {
                 constexpr int q = decltype(q_)::value, ps = q >> 1, blk = q & 1;
                 if constexpr (!(DCVIC_W44_DBG & 32)) {
-                    const float a_ = opA[set][ps], b_ = opB[set][blk][ps];
+                    const float a_ = uA[ks][pg][ps], b_ = opB[set][blk][ps];
                     if constexpr (pg < 8) asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+a"(acc[pg * 4 + ps][blk]) : "v"(a_), "v"(b_));
                     else asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(accv[ps][blk]) : "v"(a_), "v"(b_));
                 }
                 F4_FENCE();
-                constexpr int sl = 8 * pg + q;
-                // DMA pieces: one every 4th slot, U(g + 1) first (needed right behind the barrier), then X(g + 3)
-                if constexpr (!(DCVIC_W44_DBG & 4) && (sl & 3) == 1 && sl < 36) dma_u(std::integral_constant<int, sl / 4>{}, nxt);
-                if constexpr (!(DCVIC_W44_DBG & 4) && (sl & 3) == 1 && sl >= 36 && sl < 48) dma_x(std::integral_constant<int, sl / 4 - 9>{}, nxt);
-                if constexpr (DCVIC_W44_DBG & 2) {
-                } else if constexpr (ROLE == 0) {
-                    // half A: six row loads at slots 2, 3, 6, 7, 10, 11 (landed by the wait in front of group 2), column pass in groups 2 .. 7
+                constexpr int sl = 8 * G + q;                     // 0 .. 143
+                constexpr int h = sl % 72;                        // slot inside the k-step
+                // memory: per k-step three DMA pieces of X(s + 2) (slots 1, 5, 9), then the nine weight loads of the NEXT k-step
+                // (slots 13 .. 45): during k-step 0 those of (s, k-step 1), during k-step 1 those of (s + 1, k-step 0)
+                if constexpr (!(DCVIC_W44_DBG & 4) && (h & 3) == 1 && h < 12) dma_x(std::integral_constant<int, 3 * ks + h / 4>{}, cur);
+                if constexpr (!(DCVIC_W44_DBG & 4) && (h & 3) == 1 && h >= 12 && h < 48) {
+                    if constexpr (ks == 0) u_load(std::integral_constant<int, 1>{}, std::integral_constant<int, (h / 4 - 3)>{}, wp_cur);
+                    else u_load(std::integral_constant<int, 0>{}, std::integral_constant<int, (h / 4 - 3)>{}, wp_nxt);
+                }
+                if constexpr (!(DCVIC_W44_DBG & 2)) {
+                    // transform of X(s + 1): six row loads at slots 2, 3, 6, 7, 10, 11 (landed by the wait in front of group 2), column pass
+                    // at the even slots of 16 .. 62, row pass at the even slots of 72 .. 118, the twelve stores at slots 120 .. 131
                     if constexpr (sl < 12 && (sl & 3) >= 2) t_load(std::integral_constant<int, ((sl / 4) * 2 + (sl & 1))>{}, xaddr);
                     if constexpr (sl >= 16 && sl < 64 && (sl & 1) == 0)
                         t_col(std::integral_constant<int, (((sl - 16) / 2) / 4)>{}, std::integral_constant<int, (((sl - 16) / 2) % 4)>{});
-                } else {
-                    // half B: row pass in groups 0 .. 5, the twelve stores in groups 6 - 7 (landed by the wait in front of the barrier)
-                    if constexpr (sl < 48 && (sl & 1) == 0) t_row(std::integral_constant<int, ((sl / 2) / 4)>{}, std::integral_constant<int, ((sl / 2) % 4)>{});
-                    if constexpr (sl >= 48 && sl < 60) t_store(std::integral_constant<int, sl - 48>{}, vaddr);
+                    if constexpr (sl >= 72 && sl < 120 && (sl & 1) == 0)
+                        t_row(std::integral_constant<int, (((sl - 72) / 2) / 4)>{}, std::integral_constant<int, (((sl - 72) / 2) % 4)>{});
+                    if constexpr (sl >= 120 && sl < 132) t_store(std::integral_constant<int, sl - 120>{}, vaddr);
                 }
                 F4_FENCE();
             });
         });
         F4_FENCE();
     };
-    // Wave pair p runs half A in the stages g = p (mod 2) and half B in the others.  S is even (host check), so the stream length is
-    // even and a tile always ends on an odd g: the loop advances two stages per iteration, each pair with its own straight-line
-    // body -- one copy of the stream bookkeeping and of the tile epilogue per loop.
-    auto stream = [&](auto first_role_, auto second_role_) __attribute__((always_inline)) {
-        int g = 0;
+    {
+        int s = 0;
         for (int t = 0; t < ntile; ++t) {
             // the accumulators are (re)defined HERE, outside the stage loop, and die in the epilogue: one plain loop-carried live range
-            // each.  (Zeroing them inside a conditional epilogue in a flat stage loop made hipcc shuffle all 256 AGPRs through scratch at
-            // the loop header.)
+            // each.  (Zeroing them inside a conditional epilogue in a flat stage loop made hipcc shuffle all 256 AGPRs through scratch.)
 #pragma unroll
             for (int i = 0; i < 32; ++i)
 #pragma unroll
@@ -512,13 +496,11 @@ __global__ __launch_bounds__(F4_THREADS, 1) void conv3x3_wino44_kernel(const Con
             for (int i = 0; i < 4; ++i)
 #pragma unroll
                 for (int j = 0; j < 2; ++j) accv[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-            for (int c = 0; c < S; c += 2, g += 2) {
-                run_stage(first_role_, g);
-                if (g + 3 < total) x_advance();
-                if (g + 1 < total) u_advance();
-                run_stage(second_role_, g + 1);
-                if (g + 4 < total) x_advance();
-                if (g + 2 < total) u_advance();
+            for (int c = 0; c < S; ++c, ++s) {
+                run_stage(s);
+                if (s + 2 < total) x_advance();                   // the DMA of this stage fetched X(s + 2): on to X(s + 3)
+                wp_cur = wp_nxt;
+                if (s + 2 < total) u_advance();                   // wp_nxt: slab of stage s + 2
             }
             if constexpr (!(DCVIC_W44_DBG & 16)) tile_epilogue(c_cotile, c_n, c_oy0, c_ox0, c_par);
             c_b += J; c_par ^= 1;
@@ -527,9 +509,7 @@ __global__ __launch_bounds__(F4_THREADS, 1) void conv3x3_wino44_kernel(const Con
                 stage_bias(c_b, c_par);
             }
         }
-    };
-    if (pair == 0) stream(std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{});
-    else stream(std::integral_constant<int, 1>{}, std::integral_constant<int, 0>{});
+    }
 #undef F4_FENCE
 #undef F4_WAIT_LDS
 }
@@ -553,7 +533,7 @@ extern "C" int dcvic_conv3x3_wino44_f32(int Cin, int Cout, const float* packed, 
     DCVIC_CHECK_ARG(io->n_src >= 1 && io->n_src <= DCVIC_MAX_SRC, "conv3x3_wino44: n_src %d", io->n_src);
     int csum = 0;
     for (int i = 0; i < io->n_src; ++i) {
-        DCVIC_CHECK_ARG(io->src[i].ptr && io->src[i].C > 0 && io->src[i].C % F4_KC == 0, "conv3x3_wino44: source %d needs a multiple of 4 channels", i);
+        DCVIC_CHECK_ARG(io->src[i].ptr && io->src[i].C > 0 && io->src[i].C % F4_KC == 0, "conv3x3_wino44: source %d needs a multiple of 8 channels", i);
         DCVIC_CHECK_ARG(io->src[i].batch_stride >= (long long)io->src[i].C * io->H * io->W, "conv3x3_wino44: source %d batch stride too small", i);
         DCVIC_CHECK_ARG((reinterpret_cast<uintptr_t>(io->src[i].ptr) & 15) == 0 && (io->src[i].batch_stride & 3) == 0,
                         "conv3x3_wino44: source %d must be 16-byte aligned (16-byte LDS-DMA segments)", i);
@@ -564,7 +544,6 @@ extern "C" int dcvic_conv3x3_wino44_f32(int Cin, int Cout, const float* packed, 
     DCVIC_CHECK_ARG(io->Hout == io->H && io->Wout == io->W && io->Hfull == io->H && io->Wfull == io->W && io->osy == 1 && io->osx == 1 &&
                     io->ooy == 0 && io->oox == 0, "conv3x3_wino44: stride-1 pad-1 geometry only");
     DCVIC_CHECK_ARG((io->W & 3) == 0, "conv3x3_wino44: width must be a multiple of 4");
-    DCVIC_CHECK_ARG((Cin & 7) == 0, "conv3x3_wino44: Cin must be a multiple of 8 (an even number of 4-channel stages per tile)");
     DCVIC_CHECK_ARG(!io->aff_scale && !io->aff_shift && !io->init, "conv3x3_wino44: affine / init epilogues are not supported");
     DCVIC_CHECK_ARG(io->act == DCVIC_ACT_NONE || io->act == DCVIC_ACT_RELU || io->act == DCVIC_ACT_LRELU02,
                     "conv3x3_wino44: activation %d not supported (none / ReLU / LeakyReLU(0.2) only)", io->act);

@@ -78,7 +78,7 @@ class VqDecFusionModule(nn.Module):
             assert isinstance(v, dict) and "cond_ch" in v and "dec_ch" in v
         self.fusion_modules = nn.ModuleDict({k: FuseSftBlock(v["cond_ch"], v["dec_ch"], v["mid_ch"]) for k, v in fuse_scedule_dict.items()})
         self.fusion_keys = list(fuse_scedule_dict.keys())
-        allow_winograd(self)      # decoder side, after the last integer decision (see layers.allow_winograd)
+        allow_winograd(self, f44=True)      # decoder side, after the last integer decision (see layers.allow_winograd)
         for k in self.fusion_keys:
             assert k.startswith("block_1_"), "before_mid / after_mid fusion points are not used by the shipped configs"
 

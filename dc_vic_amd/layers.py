@@ -33,6 +33,7 @@ class _Packed(nn.Module):
             self._plan = self._build_plan()
             self._plan_key = k
         self._plan.wino = bool(getattr(self, "wino", False))
+        self._plan.wino44 = bool(getattr(self, "wino44", False))
         return self._plan
 
     def _build_plan(self):
@@ -53,6 +54,7 @@ class Conv2d(_Packed):
         self.kernel_size, self.stride, self.padding = kernel_size, stride, padding
         self.asym_pad, self.upsample = asym_pad, upsample
         self.wino = False     # allow_winograd(): set only where no integer decision depends on this layer's exact bits
+        self.wino44 = False   # allow_winograd(f44=True): F(4x4, 3x3) too -- only AFTER the path's last integer decision
         self.weight = nn.Parameter(torch.empty(out_ch, in_ch, kernel_size, kernel_size), requires_grad=False)
         self.bias = nn.Parameter(torch.empty(out_ch), requires_grad=False) if bias else None
         nn.init.kaiming_uniform_(self.weight, a=math.sqrt(5))
@@ -74,8 +76,12 @@ class Conv2d(_Packed):
         return plan(x, out=out, act=act, res=res, affine=affine, out_hw=out_hw)
 
 
-def allow_winograd(module: nn.Module, on: bool = True) -> nn.Module:
-    """Let every Conv2d(k3, s1, p1) under `module` run as Winograd F(2x2, 3x3) (csrc/wino.hip) when the launch is eligible.
+def allow_winograd(module: nn.Module, on: bool = True, f44: bool = False) -> nn.Module:
+    """Let every Conv2d(k3, s1, p1) under `module` run as Winograd F(2x2, 3x3) (csrc/wino.hip) when the launch is eligible; with
+    `f44` also as F(4x4, 3x3) (csrc/wino44.hip: 2.25 instead of 4 multiplies per output, ~3x the rounding error -- 1.5e-6 rms relative
+    per layer).  `f44` is passed ONLY by the frozen VQGAN decoder and the SFT fusion blocks, the layers after the estimator's argmax,
+    where nothing but the reconstruction's fp tolerance (contract 1e-3, measured in tests/parity_util.py) depends on the bits; never by
+    the encoder side, whose bits feed the VQ argmin and the symbol rounding.  `DCVIC_WINO44=0` keeps those layers on F(2x2).
 
     Winograd re-associates the sum (1e-6 relative against the direct fmaf chain; closer to fp64 than the direct chain).  Callers:
       * the frozen VQGAN decoder and the SFT fusion blocks -- the layers after the path's last integer decision (the estimator
@@ -89,6 +95,7 @@ def allow_winograd(module: nn.Module, on: bool = True) -> nn.Module:
     for m in module.modules():
         if isinstance(m, Conv2d) and m.kernel_size == 3 and m.stride == 1 and m.padding == 1 and not m.asym_pad:   # (incl. the Upsample convs)
             m.wino = on
+            m.wino44 = bool(on and f44)
     return module
 
 

@@ -131,7 +131,7 @@ def shape_stats_report() -> str:
 # ------------------------------------------------------------------------------------------- conv
 # Winograd F(2x2,3x3) for the layers that opted in (ConvPlan.wino): DCVIC_WINO=0 keeps every layer on the direct kernels
 WINO_ENABLED = os.environ.get("DCVIC_WINO", "1") != "0"
-WINO44_MIN_BLOCKS = int(os.environ.get("DCVIC_WINO44_MIN_BLOCKS", "8"))   # workgroup tiles PER IMAGE below which F(2x2) / direct run
+WINO44_MIN_BLOCKS = int(os.environ.get("DCVIC_WINO44_MIN_BLOCKS", "16"))   # workgroup tiles PER IMAGE below which F(2x2) / direct run
 WINO44_ENABLED = os.environ.get("DCVIC_WINO44", "1") != "0"   # F(4x4,3x3) for the layers that opted in (ConvPlan.wino44)
 WINO_MIN_BLOCKS = int(os.environ.get("DCVIC_WINO_MIN_BLOCKS", "16"))   # workgroups PER IMAGE below which the direct kernels run
 

@@ -209,7 +209,7 @@ class Decoder(nn.Module):
             self.up.insert(0, up)
         self.norm_out = GroupNorm(block_in)
         self.conv_out = Conv2d(block_in, out_ch, 3, 1, 1)
-        allow_winograd(self)      # after the estimator argmax: only the reconstruction's fp tolerance depends on these layers
+        allow_winograd(self, f44=True)      # after the estimator argmax: only the reconstruction's fp tolerance depends on these layers
 
     def forward(self, z: Tensor) -> Tensor:
         self.last_z_shape = z.shape
