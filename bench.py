@@ -223,7 +223,7 @@ def main():
             # HBM traffic per launch of that kernel: PMC counters need rocprofv3 (separate --pmc passes, see
             # tools/pmc_summary.py); the committed summary of the same command is reported when present
             traffic, traffic_src = None, None
-            for pmf in ("r2_pmc_traffic.json", "r2_direct_pmc_traffic.json", "r1_pmc_traffic.json"):
+            for pmf in ("r3_pmc_traffic.json", "r2_pmc_traffic.json", "r2_direct_pmc_traffic.json", "r1_pmc_traffic.json"):
                 try:
                     with open(os.path.join(ROOT, "profiles", pmf)) as f:
                         pm = json.load(f)
