@@ -14,7 +14,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 OUT = os.path.join(os.path.dirname(HERE), "libdcvic_hip.so")
-SOURCES = ["conv.hip", "conv3x3.hip", "wino.hip", "wino44.hip", "conv_async.hip", "conv_async16.hip", "conv1x1.hip", "gemm.hip", "attn.hip", "norm.hip", "ew.hip", "swin.hip", "vq.hip", "rate.hip", "train.hip", "error.cpp", "host_entropy.cpp"]
+SOURCES = ["conv.hip", "conv3x3.hip", "wino.hip", "wino44.hip", "thin.hip", "conv_async.hip", "conv_async16.hip", "conv1x1.hip", "gemm.hip", "attn.hip", "norm.hip", "ew.hip", "swin.hip", "vq.hip", "rate.hip", "train.hip", "error.cpp", "host_entropy.cpp"]
 HEADERS = [os.path.join(HERE, "common.h"), os.path.join(HERE, "conv_common.h"), os.path.join(ROOT, "include", "dcvic.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wno-unused-value", "-Wno-unused-result",
          f"-I{os.path.join(ROOT, 'include')}", f"-I{HERE}"]

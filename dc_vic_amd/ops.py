@@ -70,6 +70,10 @@ def conv_kernel_name(variant: int) -> str:
         return "conv3x3_wino_ups_kernel(ConvKArgs)"
     if variant == 9104:
         return "conv3x3_wino44_kernel(ConvKArgs)"
+    if 9200 <= variant < 9210:
+        return f"void thin_cout_kernel<{variant - 9200}>(ThinArgs)"
+    if 9210 <= variant < 9220:
+        return f"void thin_cin_kernel<{variant - 9210}>(ThinArgs)"
     if 7000 <= variant < 8000:                       # conv1x1.hip: 7000 + cls
         return f"void conv1x1_dma_kernel<{(128, 64, 32, 96)[variant - 7000]}>(ConvKArgs)"
     if 8500 <= variant < 9000:                       # conv_async16.hip: 8500 + cls*100 + P/32 (tiles in units of 16)
@@ -131,6 +135,8 @@ def shape_stats_report() -> str:
 # ------------------------------------------------------------------------------------------- conv
 # Winograd F(2x2,3x3) for the layers that opted in (ConvPlan.wino): DCVIC_WINO=0 keeps every layer on the direct kernels
 WINO_ENABLED = os.environ.get("DCVIC_WINO", "1") != "0"
+THIN_MIN_PIXELS = int(os.environ.get("DCVIC_THIN_MIN_PIXELS", "16384"))   # full-resolution maps only (the 4-channel latent convs at 1/8 stay on the MFMA kernels)
+THIN_ENABLED = os.environ.get("DCVIC_THIN", "1") != "0"       # VALU kernels for the 3 -> 128 / 128 -> 3 layers (csrc/thin.hip)
 WINO44_MIN_BLOCKS = int(os.environ.get("DCVIC_WINO44_MIN_BLOCKS", "16"))   # workgroup tiles PER IMAGE below which F(2x2) / direct run
 WINO44_ENABLED = os.environ.get("DCVIC_WINO44", "1") != "0"   # F(4x4,3x3) for the layers that opted in (ConvPlan.wino44)
 WINO_MIN_BLOCKS = int(os.environ.get("DCVIC_WINO_MIN_BLOCKS", "16"))   # workgroups PER IMAGE below which the direct kernels run
@@ -238,12 +244,12 @@ class ConvPlan:
         return ty * tx * ((self.Cout + 63) // 64) >= WINO_MIN_BLOCKS
 
     def _wino44_ok(self, srcs, N: int, H: int, W: int) -> bool:
-        """F(4x4, 3x3) eligibility: Conv2d(k3, s1, p1), Cin % 8 == 0 with 4-channel-aligned sources, width % 4 == 0, and a map that
-        fills its 64-channel x 16 x 32-pixel workgroup tiles.  A function of the layer and the image size only, never of N."""
+        """F(4x4, 3x3) eligibility: Conv2d(k3, s1, p1), every source a multiple of 8 channels, width % 4 == 0, and a map that fills its
+        64-channel x 16 x 32-pixel workgroup tiles.  A function of the layer and the image size only, never of N."""
         if self.kind != "conv" or self.upsample or self.ups_phases or self.stride != 1 or self.pad != (1, 1) \
                 or (self.KH, self.KW) != (3, 3) or self._w is None:
             return False
-        if (W & 3) or self.Cout < 48 or self.Cin % 8 or any(s.shape[1] % 4 or s.data_ptr() % 16 or (s.shape[0] > 1 and s.stride(0) % 4) for s in srcs):
+        if (W & 3) or self.Cout < 48 or any(s.shape[1] % 8 or s.data_ptr() % 16 or (s.shape[0] > 1 and s.stride(0) % 4) for s in srcs):
             return False
         ty, tx = (H + 15) // 16, (W + 31) // 32
         if H * W < 0.6 * (ty * 16 * tx * 32):
@@ -326,6 +332,24 @@ class ConvPlan:
             if sc.shape[0] not in (1, N):
                 raise ValueError("conv affine batch must be 1 or N")
         st = _stream()
+        if THIN_ENABLED and self.kind == "conv" and not self.upsample and not self.ups_phases and self.stride == 1 and self.pad == (1, 1) \
+                and (self.KH, self.KW) == (3, 3) and self._w is not None and len(srcs) == 1 and init is None and affine is None \
+                and (out_hw is None or tuple(out_hw) == (H, W)) and H * W >= THIN_MIN_PIXELS \
+                and lib().dcvic_conv3x3_thin_applies(self.Cin, self.Cout):
+            # a thin layer (VQGAN conv_in 3 -> 128, conv_out 128 -> 3): HBM-bound VALU kernel, bit-identical to the MFMA kernels' order
+            io.Hout, io.Wout = Hf, Wf
+            io.osy = io.osx = 1
+            io.ooy = io.oox = 0
+            var = 9200 + self.Cout if self.Cout <= 4 and self.Cin >= 8 else 9210 + self.Cin
+            if _EVENTS is not None:
+                e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+                e0.record()
+                check(lib().dcvic_conv3x3_thin_f32(_p(self._w), self.Cin, self.Cout, C.byref(io), st), "conv3x3_thin")
+                e1.record()
+                _EVENTS.append((var, 2.0 * N * H * W * self.Cout * self.Cin * 9, e0, e1, (self.Cin, self.Cout, 9, 1, 0, H, W, N)))
+            else:
+                check(lib().dcvic_conv3x3_thin_f32(_p(self._w), self.Cin, self.Cout, C.byref(io), st), "conv3x3_thin")
+            return out
         if self.wino44 and WINO44_ENABLED and self.wino and WINO_ENABLED and not self.ups_phases and not self.upsample and init is None and affine is None \
                 and act in (ACT_NONE, ACT_RELU, ACT_LRELU02) \
                 and (self.wino44 == "force" or self._wino44_ok(srcs, N, H, W)) \

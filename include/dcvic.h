@@ -162,12 +162,18 @@ int dcvic_conv3x3_wino_ups_f32(int Cin, int Cout, const float* packed, const dcv
  * the path's last integer decision -- the frozen VQGAN decoder and the SFT fusion blocks (same reference operators as
  * dcvic_conv3x3_wino_f32: ldm/modules/diffusionmodules/model.py:82-141, 462-568; codeformer_layers.py:20-67;
  * vq_fusion_module.py:78-126) -- where it moves the reconstruction at the 1e-5 level (contract: 1e-3) and cannot touch indices or
- * bitstreams.  io contract of dcvic_conv3x3_wino_f32, with every source a multiple of 4 channels and Cin a multiple of 8.
- * Weights: G g G^T in fp64, rounded once, packed per (64-channel tile, 4-channel chunk) as the kernel's 36 KiB LDS image.
+ * bitstreams.  io contract of dcvic_conv3x3_wino_f32 (every source a multiple of 8 channels), activation none / ReLU / LeakyReLU(0.2).
+ * Weights: G g G^T in fp64, rounded once, packed per (64-channel tile, 8-channel chunk) in the order the waves load them into registers.
  * Deterministic and batch-invariant. */
 size_t dcvic_wino44_packed_bytes(int Cin, int Cout);
 int dcvic_wino44_pack_f32(const float* w, float* packed, int Cin, int Cout, void* stream);
 int dcvic_conv3x3_wino44_f32(int Cin, int Cout, const float* packed, const dcvic_conv_io* io, void* stream);
+/* Conv2d(k3, s1, p1) with Cout <= 4 (Cin % 8 == 0) or Cin <= 4 (csrc/thin.hip): the VQGAN decoder's conv_out (128 -> 3,
+ * ldm/modules/diffusionmodules/model.py:553-557) and the VQGAN encoder's conv_in (3 -> 128, model.py:388-392).  HBM-bound fp32
+ * fmaf chains on the vector ALU in exactly the reduction order of dcvic_conv2d_f32, hence BIT-IDENTICAL to it; unpacked weights
+ * w[Cout][Cin][3][3]; one source; epilogue bias -> act -> (+res).  dcvic_conv3x3_thin_applies: 1 if the layer qualifies. */
+int dcvic_conv3x3_thin_applies(int Cin, int Cout);
+int dcvic_conv3x3_thin_f32(const float* w, int Cin, int Cout, const dcvic_conv_io* io, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Batched strided GEMM  C[b][m][n] = alpha * sum_k A[b][m][k] * B[b][k][n]

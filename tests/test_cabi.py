@@ -49,3 +49,8 @@ def test_wino_packed_bytes_host_formula():
     for cin, cout in ((128, 128), (704, 512), (8, 64), (20, 96), (256, 3)):
         assert L.dcvic_wino_packed_bytes(cin, cout) == ((cout + 63) // 64) * ((cin + 7) // 8) * 16 * 8 * 64 * 4
     assert L.dcvic_wino_packed_bytes(0, 64) == 0
+    # F(4x4, 3x3): one 72 KiB slab (2 k-steps x 36 positions x 4 channels x 64 output channels) per (64-channel tile, 8-channel chunk)
+    L.dcvic_wino44_packed_bytes.restype = C.c_size_t
+    for cin, cout in ((256, 256), (704, 512), (8, 64), (128, 200)):
+        assert L.dcvic_wino44_packed_bytes(cin, cout) == ((cout + 63) // 64) * ((cin + 7) // 8) * 2 * 36 * 4 * 64 * 4
+    assert L.dcvic_wino44_packed_bytes(64, 0) == 0

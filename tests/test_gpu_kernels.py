@@ -802,3 +802,175 @@ def test_wino_fuzz_vs_direct(dev):
         sc = float(yd.abs().max())
         err = float((yd - yw).abs().max()) / max(sc, 1e-6)
         assert err < 5e-6, (it, ups, cs, Cout, H, W, N, act, res, err)
+
+
+# ------------------------------------------------------------------------------------------- Winograd F(4x4, 3x3) (csrc/wino44.hip)
+@pytest.mark.parametrize("case", [
+    (8, 64, 8, 32, 1, None, False, 0), (16, 64, 10, 28, 2, None, False, 1), (64, 128, 33, 72, 2, None, True, 2),
+    (128, 192, 64, 64, 2, None, True, 0), (256, 128, 40, 48, 1, [192, 64], False, 0), (704, 512, 32, 32, 2, [192, 512], False, 0),
+    (8, 200, 19, 36, 3, None, True, 0)])
+def test_wino44_conv3x3(dev, case):
+    """dcvic_conv3x3_wino44_f32 (F(4x4, 3x3), points 0, +-3/4, +-3/2, inf) vs torch conv2d in fp64: 1.2e-5 of the output's max -- 4x the
+    largest error measured on MI355X over these cases (2.9e-6); the direct kernel's error against the same reference is 2.8e-7 ..
+    1.8e-6, F(2x2)'s 1.4e-7 .. 4.8e-7 (test_wino_conv3x3).  Cases: one stage, several stages, ragged maps with partial tiles in both
+    directions, residual, ReLU / LeakyReLU epilogues, two sources switching inside the stage stream (the SFT fusion's 192 + 512
+    channel concat buffer), Cout not a multiple of 64."""
+    from dc_vic_amd import ops
+    Cin, Cout, H, W, N, split, res, act = case
+    x = rnd(N, Cin, H, W, seed=51)
+    w = rnd(Cout, Cin, 3, 3, seed=52, scale=(Cin * 9) ** -0.5)
+    b = rnd(Cout, seed=53, scale=0.1)
+    r = rnd(N, Cout, H, W, seed=54) if res else None
+    ref = F.conv2d(x.double(), w.double(), b.double(), padding=1)
+    if act == 1:
+        ref = torch.relu(ref)
+    elif act == 2:
+        ref = torch.where(ref > 0, ref, 0.2 * ref)
+    if res:
+        ref = ref + r.double()
+    plan = ops.ConvPlan(w.to(dev), b.to(dev), "conv", pad=(1, 1))
+    plan.wino = plan.wino44 = "force"
+    xs = x.to(dev)
+    srcs = xs if split is None else [t.contiguous() for t in torch.split(xs, split, dim=1)]
+    rd = r.to(dev) if res else None
+    ops.kernel_events_start()
+    y = plan(srcs, act=act, res=rd)
+    torch.cuda.synchronize()
+    ev = ops.kernel_events_stop()
+    assert list(ev) == ["conv3x3_wino44_kernel(ConvKArgs)"], list(ev)           # the F(4x4) kernel really ran
+    err = float((y.double().cpu() - ref).abs().max()) / float(ref.abs().max())
+    assert err < 1.2e-5, err
+
+
+def test_wino44_batch_invariant_deterministic_and_variants(dev):
+    """The tile grid and the per-position reduction order never depend on N: an image convolved alone, inside a batch, or in a batch
+    large enough for the persistent workgroups to walk several tiles gives the same bits, and so do two runs.  The result stays within
+    5e-6 of the F(2x2) kernel and 1.2e-5 of the direct one on the same data."""
+    from dc_vic_amd import ops
+    x = rnd(9, 128, 64, 96, seed=61).to(dev)
+    w = rnd(256, 128, 3, 3, seed=62, scale=(128 * 9) ** -0.5).to(dev)
+    b = rnd(256, seed=63).to(dev)
+    p44 = ops.ConvPlan(w, b, "conv", pad=(1, 1)); p44.wino = p44.wino44 = "force"
+    p22 = ops.ConvPlan(w, b, "conv", pad=(1, 1)); p22.wino = "force"
+    pd = ops.ConvPlan(w, b, "conv", pad=(1, 1))
+    y9, y9b = p44(x), p44(x)
+    y1 = p44(x[3:4].contiguous())
+    y64 = p44(x.repeat(8, 1, 1, 1)[:64].contiguous())
+    assert torch.equal(y9, y9b) and torch.equal(y9[3:4], y1) and torch.equal(y64[3:4], y1) and torch.equal(y64[9 + 3:9 + 4], y1)
+    sc = float(pd(x).abs().max())
+    assert float((y9 - p22(x)).abs().max()) / sc < 1.2e-5 and float((y9 - pd(x)).abs().max()) / sc < 1.2e-5
+
+
+def test_wino44_eligibility_and_fallbacks(dev):
+    """ConvPlan._wino44_ok is a function of the layer and the image size only (never of N), refuses widths that are not a multiple of 4,
+    Cin not a multiple of 8, maps that waste the 16 x 32 tiles, and the transcendental epilogues; such launches run on F(2x2) or the
+    direct kernels.  DCVIC_WINO44=0 (ops.WINO44_ENABLED) switches the layer class back to F(2x2)."""
+    from dc_vic_amd import ops
+    w = rnd(128, 128, 3, 3, seed=71, scale=0.03).to(dev)
+    plan = ops.ConvPlan(w, None, "conv", pad=(1, 1))
+    plan.wino = plan.wino44 = True
+    mk = lambda n, c, h, ww: [torch.empty((n, c, h, ww), device=dev)]
+    assert plan._wino44_ok(mk(1, 128, 256, 256), 1, 256, 256) and plan._wino44_ok(mk(32, 128, 256, 256), 32, 256, 256)
+    assert plan._wino44_ok(mk(1, 128, 32, 32), 1, 32, 32) == plan._wino44_ok(mk(32, 128, 32, 32), 32, 32, 32)
+    assert not plan._wino44_ok(mk(1, 128, 64, 62), 1, 64, 62)          # width not a multiple of 4
+    assert not plan._wino44_ok(mk(1, 128, 8, 8), 1, 8, 8)              # 8 x 8 map in a 16 x 32 tile
+    assert not plan._wino44_ok([torch.empty((1, 124, 64, 64), device=dev), torch.empty((1, 4, 64, 64), device=dev)], 1, 64, 64)
+
+    def kernel_of(p, x, **kw):
+        ops.kernel_events_start()
+        p(x, **kw)
+        torch.cuda.synchronize()
+        return list(ops.kernel_events_stop())
+    x = torch.zeros((1, 128, 128, 128), device=dev)
+    assert kernel_of(plan, x) == ["conv3x3_wino44_kernel(ConvKArgs)"]
+    assert kernel_of(plan, x, act=ops.ACT_SWISH) == ["void conv3x3_wino_kernel<0>(ConvKArgs)"]       # swish epilogue: F(2x2)
+    assert "wino" not in kernel_of(plan, torch.zeros((1, 128, 8, 8), device=dev))[0]                   # tiny map: direct kernel
+    old = ops.WINO44_ENABLED
+    ops.WINO44_ENABLED = False
+    try:
+        assert kernel_of(plan, x) == ["void conv3x3_wino_kernel<0>(ConvKArgs)"]
+    finally:
+        ops.WINO44_ENABLED = old
+
+
+def test_wino44_only_behind_the_last_integer_decision(dev):
+    """F(4x4) has ~3x the rounding error of F(2x2): the model may enable it ONLY on the frozen VQGAN decoder and the SFT fusion
+    blocks (after the estimator's argmax).  Encoder-side and entropy-side layers must never carry the flag."""
+    import os
+    from dc_vic_amd import BaseConfig, build_comp_model
+    from dc_vic_amd.layers import Conv2d
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    m = build_comp_model(BaseConfig.fromfile(os.path.join(root, "config", "dc_vic_synthetic.yaml"), {"device": dev}))
+    on = {n for n, mod in m.named_modules() if isinstance(mod, Conv2d) and getattr(mod, "wino44", False)}
+    assert on and all(n.startswith(("vq_model.decoder.", "fusion_module.")) for n in on), sorted(on)[:5]
+    for prefix in ("vq_model.encoder.", "encoder.", "decoder.", "hyperencoder.", "hyperdecoder.", "context_model.", "vq_estimator."):
+        assert not any(n.startswith(prefix) for n in on), prefix
+    assert any(n.startswith("vq_model.decoder.up.") for n in on) and any(n.startswith("fusion_module.fusion_modules.") for n in on)
+
+
+def test_wino44_fuzz_vs_direct(dev):
+    """30 random layer geometries (channels, ragged sizes, 1-3 sources, residual, ReLU / LeakyReLU, batch) through the F(4x4) kernel
+    against the direct kernels: 1.5e-5 of the output's max.  Exercises the persistent tile loop (more tiles than workgroups), partial
+    tiles in both directions, channel tiles beyond Cout and source switches inside a tile's stage stream."""
+    from dc_vic_amd import ops
+    rng = np.random.RandomState(17)
+    for it in range(30):
+        n_src = int(rng.randint(1, 4))
+        cs = [8 * int(rng.randint(1, 9)) for _ in range(n_src)]
+        Cin = sum(cs)
+        Cout = int(rng.choice([48, 64, 96, 128, 192, 200, 256]))
+        H = int(rng.randint(3, 41))
+        W = 4 * int(rng.randint(1, 25))
+        N = int(rng.randint(1, 6))
+        act = int(rng.choice([0, 1, 2]))
+        res = bool(rng.randint(0, 2))
+        x = rnd(N, Cin, H, W, seed=500 + it)
+        w = rnd(Cout, Cin, 3, 3, seed=600 + it, scale=(Cin * 9) ** -0.5)
+        b = rnd(Cout, seed=700 + it, scale=0.1)
+        r = rnd(N, Cout, H, W, seed=800 + it).to(dev) if res else None
+        direct = ops.ConvPlan(w.to(dev), b.to(dev), "conv", pad=(1, 1))
+        f44 = ops.ConvPlan(w.to(dev), b.to(dev), "conv", pad=(1, 1))
+        f44.wino = f44.wino44 = "force"
+        xs = x.to(dev)
+        srcs = [t.contiguous() for t in torch.split(xs, cs, dim=1)] if n_src > 1 else xs
+        yd = direct(srcs, act=act, res=r)
+        yw = f44(srcs, act=act, res=r)
+        sc = float(yd.abs().max())
+        err = float((yd - yw).abs().max()) / max(sc, 1e-6)
+        assert err < 1.5e-5, (it, cs, Cout, H, W, N, act, res, err)
+
+
+# ------------------------------------------------------------------------------------------- thin layers (csrc/thin.hip)
+@pytest.mark.parametrize("case", [(128, 3, 70, 100, 2, True, 0), (128, 3, 256, 256, 1, False, 0), (64, 4, 9, 130, 3, False, 3), (8, 1, 5, 7, 1, True, 1),
+                                  (3, 128, 70, 100, 2, False, 0), (3, 128, 256, 256, 1, False, 0), (4, 40, 9, 130, 3, True, 2), (1, 16, 5, 7, 2, False, 3)])
+def test_thin_conv_bit_identical_to_the_mfma_kernels(dev, case):
+    """dcvic_conv3x3_thin_f32 (VQGAN conv_in 3 -> 128, conv_out 128 -> 3: HBM-bound VALU kernels) runs the fmaf chain in exactly the
+    order of the MFMA kernels it replaces, so the outputs are equal BIT FOR BIT (incl. ragged sizes, bias / residual / activation
+    epilogues) -- no tolerance, no parity question up- or downstream."""
+    from dc_vic_amd import ops
+    Cin, Cout, H, W, N, res, act = case
+    x = rnd(N, Cin, H, W, seed=91).to(dev)
+    w = rnd(Cout, Cin, 3, 3, seed=92, scale=(Cin * 9) ** -0.5).to(dev)
+    b = rnd(Cout, seed=93, scale=0.1).to(dev)
+    r = rnd(N, Cout, H, W, seed=94).to(dev) if res else None
+    plan = ops.ConvPlan(w, b, "conv", pad=(1, 1))
+    old_min, ops.THIN_MIN_PIXELS = ops.THIN_MIN_PIXELS, 0         # (the model uses the thin kernels on full-resolution maps only)
+    ops.kernel_events_start()
+    y_thin = plan(x, act=act, res=r)
+    torch.cuda.synchronize()
+    ev = list(ops.kernel_events_stop())
+    assert len(ev) == 1 and "thin_" in ev[0], ev
+    old = ops.THIN_ENABLED
+    ops.THIN_ENABLED = False
+    try:
+        ops.kernel_events_start()
+        y_mfma = plan(x, act=act, res=r)
+        torch.cuda.synchronize()
+        ev2 = list(ops.kernel_events_stop())
+    finally:
+        ops.THIN_ENABLED = old
+    assert "thin_" not in ev2[0]
+    assert torch.equal(y_thin, y_mfma), float((y_thin - y_mfma).abs().max())
+    y1 = plan(x[:1].contiguous(), act=act, res=None if r is None else r[:1].contiguous())
+    ops.THIN_MIN_PIXELS = old_min
+    assert torch.equal(y1, y_thin[:1])                            # batch-invariant
