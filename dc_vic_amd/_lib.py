@@ -60,6 +60,7 @@ SYMBOLS = [
     "dcvic_wino_ups_packed_bytes", "dcvic_wino_ups_pack_f32", "dcvic_conv3x3_wino_ups_f32",
     "dcvic_wino44_packed_bytes", "dcvic_wino44_pack_f32", "dcvic_conv3x3_wino44_f32",
     "dcvic_conv3x3_thin_applies", "dcvic_conv3x3_thin_f32",
+    "dcvic_wino44_stats_tiles", "dcvic_conv3x3_wino44_stats_f32", "dcvic_groupnorm_part_f32",
     "dcvic_bgemm_f32", "dcvic_attn_fused_f32", "dcvic_groupnorm_f32", "dcvic_layernorm_c_f32", "dcvic_softmax_c_f32", "dcvic_swin_attn_f32",
     "dcvic_ew_f32", "dcvic_chan_affine_f32", "dcvic_copy_planes_f32", "dcvic_copy_window_f32", "dcvic_absmax_f32", "dcvic_crop_clamp_f32",
     "dcvic_vq_argmin_f32", "dcvic_argmax_lut_f32", "dcvic_gaussian_rate_f32", "dcvic_rate_blocks", "dcvic_neglog2_sum_f32", "dcvic_eb_rate_f32",

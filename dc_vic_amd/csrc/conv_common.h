@@ -34,6 +34,7 @@ struct ConvKArgs {
     int TG, CPS, n_chunks, n_cotiles;
     int nblocks;
     int halves;               // 2: 3x3/stride-1 family order (4-channel half, tap, channel); 1: (tap, channel)
+    float* gn_part;           // wino44 only: per (image, output channel, pixel tile) partial (sum, sum of squares) of the stored output, or null
 };
 
 

@@ -36,7 +36,7 @@ __device__ __forceinline__ double block_sum_d(double v, double* red) {
 __global__ __launch_bounds__(512) void groupnorm_kernel(const float* __restrict__ x, long long x_bs, float* __restrict__ y,
                                                         long long y_bs, const float* __restrict__ gamma,
                                                         const float* __restrict__ beta, int C, int HW, int groups, float eps,
-                                                        int act) {
+                                                        int act, const float* __restrict__ part, int n_pt) {
     __shared__ double redd[16];
     const int n = blockIdx.x / groups, g = blockIdx.x % groups;
     const int cg = C / groups;
@@ -47,7 +47,12 @@ __global__ __launch_bounds__(512) void groupnorm_kernel(const float* __restrict_
     // one statistics pass: sum and sum of squares accumulated in fp64 (E[x^2] - mean^2 is then exact to fp32
     // accuracy, no second read of the group), reduced in a fixed order
     double s = 0.0, q = 0.0;
-    if (vec) {
+    if (part) {
+        // statistics handed over by the producing convolution (csrc/wino44.hip epilogue): per (channel, pixel tile) partial sums of the
+        // very values stored in x; the cg * n_pt pairs of this group are contiguous.  Added in fp64, fixed order: no read of x here.
+        const float2* pp = reinterpret_cast<const float2*>(part) + ((long long)n * C + (long long)g * cg) * n_pt;
+        for (int i = threadIdx.x; i < cg * n_pt; i += blockDim.x) { const float2 v = pp[i]; s += (double)v.x; q += (double)v.y; }
+    } else if (vec) {
         const float4* x4 = reinterpret_cast<const float4*>(xp);
         for (long long i = threadIdx.x; i < len / 4; i += blockDim.x) {
             const float4 v = x4[i];
@@ -89,8 +94,19 @@ extern "C" int dcvic_groupnorm_f32(const float* x, long long x_bs, float* y, lon
     DCVIC_CHECK_ARG(x && y && gamma && beta, "groupnorm: null pointer");
     DCVIC_CHECK_ARG(N > 0 && C > 0 && HW > 0 && groups > 0 && C % groups == 0, "groupnorm: C=%d groups=%d", C, groups);
     DCVIC_CHECK_ARG(x_bs >= (long long)C * HW && y_bs >= (long long)C * HW, "groupnorm: batch stride too small");
-    groupnorm_kernel<<<N * groups, 512, 0, (hipStream_t)stream>>>(x, x_bs, y, y_bs, gamma, beta, C, HW, groups, eps, act);
+    groupnorm_kernel<<<N * groups, 512, 0, (hipStream_t)stream>>>(x, x_bs, y, y_bs, gamma, beta, C, HW, groups, eps, act, nullptr, 0);
     DCVIC_CHECK_LAUNCH("groupnorm");
+    return DCVIC_OK;
+}
+
+extern "C" int dcvic_groupnorm_part_f32(const float* x, long long x_bs, float* y, long long y_bs, const float* gamma,
+                                        const float* beta, int N, int C, int HW, int groups, float eps, int act,
+                                        const float* part, int n_pt, void* stream) {
+    DCVIC_CHECK_ARG(x && y && gamma && beta && part && n_pt > 0, "groupnorm_part: null pointer / no tiles");
+    DCVIC_CHECK_ARG(N > 0 && C > 0 && HW > 0 && groups > 0 && C % groups == 0, "groupnorm_part: C=%d groups=%d", C, groups);
+    DCVIC_CHECK_ARG(x_bs >= (long long)C * HW && y_bs >= (long long)C * HW, "groupnorm_part: batch stride too small");
+    groupnorm_kernel<<<N * groups, 512, 0, (hipStream_t)stream>>>(x, x_bs, y, y_bs, gamma, beta, C, HW, groups, eps, act, part, n_pt);
+    DCVIC_CHECK_LAUNCH("groupnorm_part");
     return DCVIC_OK;
 }
 

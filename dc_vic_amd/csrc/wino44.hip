@@ -337,6 +337,7 @@ __global__ __launch_bounds__(F4_THREADS, 1) void conv3x3_wino44_kernel(const Con
         float bv[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) bv[r] = has_bias ? sbias[par * F4_CO + cg * 16 + 4 * lq + r] : 0.f;
+        float gs[4] = {0.f, 0.f, 0.f, 0.f}, gq[4] = {0.f, 0.f, 0.f, 0.f};   // GroupNorm partials of this lane's four channels
         dcvic_static_for<0, 2>([&](auto blk_) {
             constexpr int blk = decltype(blk_)::value;
             const int t = blk * 16 + e_n;
@@ -369,6 +370,7 @@ __global__ __launch_bounds__(F4_THREADS, 1) void conv3x3_wino44_kernel(const Con
                     for (int j = 0; j < 4; ++j) y[i][j] = y[i][j] > 0.f ? y[i][j] : neg_slope * y[i][j];
                 if (in_img && co0 + r < K.Cout) {
                     float* const ob = K.out + (long long)n * K.out_bs + (long long)(co0 + r) * HW + pix;
+                    const bool want_gn = K.gn_part != nullptr;
                     if (has_res) {
                         const float* const rb = K.res + (long long)n * K.res_bs + (long long)(co0 + r) * HW + pix;
                         f32x4 rv[4];
@@ -378,6 +380,14 @@ __global__ __launch_bounds__(F4_THREADS, 1) void conv3x3_wino44_kernel(const Con
                         for (int i = 0; i < 4; ++i)
 #pragma unroll
                             for (int j = 0; j < 4; ++j) y[i][j] += rv[i][j];
+                    }
+                    if (want_gn) {                                // statistics of exactly the values stored (fixed order: row, column)
+#pragma unroll
+                        for (int i = 0; i < 4; ++i)
+                            if (i < rows) {
+#pragma unroll
+                                for (int j = 0; j < 4; ++j) { gs[r] += y[i][j]; gq[r] = __builtin_fmaf(y[i][j], y[i][j], gq[r]); }
+                            }
                     }
                     if (rows >= 4) {
 #pragma unroll
@@ -390,6 +400,24 @@ __global__ __launch_bounds__(F4_THREADS, 1) void conv3x3_wino44_kernel(const Con
                 }
             }
         });
+        if (K.gn_part) {
+            // GroupNorm statistics from the producer: per (image, channel, pixel tile) the sum and the sum of squares of the
+            // 512 stored values -- 32 per lane, then the 16 lanes of a row (same four channels) by xor shuffles, everything in a fixed order.
+            // dcvic_groupnorm_part_f32 adds the tiles of a group in fp64 and skips its own statistics pass (one read of the map less).
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+#pragma unroll
+                for (int o = 1; o < 16; o <<= 1) { gs[r] += __shfl_xor(gs[r], o, 64); gq[r] += __shfl_xor(gq[r], o, 64); }
+            }
+            if (e_n == 0) {
+                const int pt = (oy0 / F4_TH) * K.tiles_x + ox0 / F4_TW;
+                const int npt = K.tiles_x * K.tiles_y;
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (co0 + r < K.Cout)
+                        *reinterpret_cast<f32x2*>(K.gn_part + (((long long)n * K.Cout + co0 + r) * npt + pt) * 2) = f32x2{gs[r], gq[r]};
+            }
+        }
     };
     auto stage_bias = [&](int b, int par) __attribute__((always_inline)) {
         if (tid < F4_CO) sbias[par * F4_CO + tid] = has_bias ? K.bias[min(cotile_of(b) * F4_CO + tid, K.Cout - 1)] : 0.f;
@@ -528,7 +556,20 @@ extern "C" int dcvic_wino44_pack_f32(const float* w, float* packed, int Cin, int
     return DCVIC_OK;
 }
 
+extern "C" int dcvic_wino44_stats_tiles(int H, int W) { return H > 0 && W > 0 ? ((H + F4_TH - 1) / F4_TH) * ((W + F4_TW - 1) / F4_TW) : 0; }
+
+static int wino44_launch(int Cin, int Cout, const float* packed, const dcvic_conv_io* io, float* gn_part, void* stream);
+
 extern "C" int dcvic_conv3x3_wino44_f32(int Cin, int Cout, const float* packed, const dcvic_conv_io* io, void* stream) {
+    return wino44_launch(Cin, Cout, packed, io, nullptr, stream);
+}
+
+extern "C" int dcvic_conv3x3_wino44_stats_f32(int Cin, int Cout, const float* packed, const dcvic_conv_io* io, float* gn_part, void* stream) {
+    DCVIC_CHECK_ARG(gn_part, "conv3x3_wino44_stats: null statistics buffer");
+    return wino44_launch(Cin, Cout, packed, io, gn_part, stream);
+}
+
+static int wino44_launch(int Cin, int Cout, const float* packed, const dcvic_conv_io* io, float* gn_part, void* stream) {
     DCVIC_CHECK_ARG(packed && io && io->out && Cin > 0 && Cout > 0, "conv3x3_wino44: null pointer");
     DCVIC_CHECK_ARG(io->n_src >= 1 && io->n_src <= DCVIC_MAX_SRC, "conv3x3_wino44: n_src %d", io->n_src);
     int csum = 0;
@@ -564,6 +605,7 @@ extern "C" int dcvic_conv3x3_wino44_f32(int Cin, int Cout, const float* packed, 
     K.out = io->out; K.out_bs = io->out_batch_stride; K.bias = io->bias; K.act = io->act;
     K.res = io->res; K.res_bs = io->res_batch_stride;
     K.wp = packed;
+    K.gn_part = gn_part;
     K.n_chunks = (Cin + F4_KC - 1) / F4_KC;
     K.n_cotiles = (Cout + F4_CO - 1) / F4_CO;
     K.tiles_y = (io->H + F4_TH - 1) / F4_TH;

@@ -44,8 +44,8 @@ class ResBlock(nn.Module):
 
     def forward(self, x_in: Tensor) -> Tensor:
         x = self.norm1(x_in, act=ops.ACT_SWISH)
-        x = self.conv1(x)
-        x = self.norm2(x, act=ops.ACT_SWISH, out=x)
+        x = self.conv1(x, gn_stats=True)              # (GroupNorm statistics from the F(4x4) epilogue: layers.Conv2d.forward)
+        x = self.norm2(x, act=ops.ACT_SWISH, out=x, part=self.conv1.take_gn_part())
         skip = self.conv_out(x_in) if self.in_channels != self.out_channels else x_in
         return self.conv2(x, res=skip)
 
@@ -107,6 +107,7 @@ class VqDecFusionModule(nn.Module):
         h = vq_dec.mid.block_1(h)
         h = vq_dec.mid.attn_1(h)
         h = vq_dec.mid.block_2(h)
+        part = None
         for i_level in reversed(range(vq_dec.num_resolutions)):
             lvl = vq_dec.up[i_level]
             key = f"block_1_{2 ** i_level}"
@@ -119,14 +120,20 @@ class VqDecFusionModule(nn.Module):
                 if fuse and last:
                     m = self.fusion_modules[key]
                     dst = cat_bufs[key][:, m.cond_ch:]
-                h = lvl.block[i_block](h, out=None if has_attn else dst)
+                # `part`: GroupNorm statistics of h from the F(4x4) epilogue of the block that produced it, while the next consumer is a
+                # GroupNorm over exactly that map (not after attention / SFT fusion / upsampling, not into a concat buffer)
+                to_cat = dst is not None and not has_attn
+                h = lvl.block[i_block](h, out=None if has_attn else dst, in_part=part, want_part=not has_attn and not to_cat)
+                part = None if (has_attn or to_cat) else lvl.block[i_block].out_part
                 if has_attn:
                     h = lvl.attn[i_block](h, out=dst)
             if fuse:
                 h = self.fusion_modules[key](cat_bufs[key], w)
+                part = None
             if i_level != 0:
                 h = lvl.upsample(h)
+                part = None
         if vq_dec.give_pre_end:
             return h
-        h = vq_dec.norm_out(h, act=ops.ACT_SWISH, out=h)
+        h = vq_dec.norm_out(h, act=ops.ACT_SWISH, out=h, part=part)
         return vq_dec.conv_out(h)

@@ -66,14 +66,23 @@ class Conv2d(_Packed):
         pad = (0, 0) if self.asym_pad else (self.padding, self.padding)
         return ops.ConvPlan(self.weight, self.bias, "conv", stride=self.stride, pad=pad, upsample=self.upsample)
 
-    def forward(self, x, act: int = ops.ACT_NONE, res: Optional[Tensor] = None, affine=None, out: Optional[Tensor] = None) -> Tensor:
+    def forward(self, x, act: int = ops.ACT_NONE, res: Optional[Tensor] = None, affine=None, out: Optional[Tensor] = None,
+                gn_stats: bool = False) -> Tensor:
+        """`gn_stats`: a GroupNorm over exactly this output follows; its statistics come out of this launch's epilogue when it runs on the
+        F(4x4) kernel (take them with `take_gn_part()`, None otherwise -- the GroupNorm then makes its own pass)."""
         plan = self._get_plan()
         out_hw = None
         if self.asym_pad:
             src0 = x if isinstance(x, Tensor) else x[0]
             H, W = src0.shape[2:]
             out_hw = ((H + 1 - self.kernel_size) // self.stride + 1, (W + 1 - self.kernel_size) // self.stride + 1)
-        return plan(x, out=out, act=act, res=res, affine=affine, out_hw=out_hw)
+        y = plan(x, out=out, act=act, res=res, affine=affine, out_hw=out_hw, gn_stats=gn_stats)
+        self._gn_part = plan.last_gn_part
+        return y
+
+    def take_gn_part(self):
+        p, self._gn_part = getattr(self, "_gn_part", None), None
+        return p
 
 
 def allow_winograd(module: nn.Module, on: bool = True, f44: bool = False) -> nn.Module:
@@ -149,8 +158,8 @@ class GroupNorm(nn.Module):
         self.weight = nn.Parameter(torch.ones(num_channels), requires_grad=False)
         self.bias = nn.Parameter(torch.zeros(num_channels), requires_grad=False)
 
-    def forward(self, x: Tensor, act: int = ops.ACT_NONE, out: Optional[Tensor] = None) -> Tensor:
-        return ops.groupnorm(x, self.weight, self.bias, self.num_groups, self.eps, act, out)
+    def forward(self, x: Tensor, act: int = ops.ACT_NONE, out: Optional[Tensor] = None, part=None) -> Tensor:
+        return ops.groupnorm(x, self.weight, self.bias, self.num_groups, self.eps, act, out, part=part)
 
 
 class LayerNormC(nn.Module):

@@ -135,6 +135,7 @@ def shape_stats_report() -> str:
 # ------------------------------------------------------------------------------------------- conv
 # Winograd F(2x2,3x3) for the layers that opted in (ConvPlan.wino): DCVIC_WINO=0 keeps every layer on the direct kernels
 WINO_ENABLED = os.environ.get("DCVIC_WINO", "1") != "0"
+GN_FUSED_STATS = os.environ.get("DCVIC_GN_FUSED", "1") != "0"   # GroupNorm statistics from the producing F(4x4) convolution's epilogue
 THIN_MIN_PIXELS = int(os.environ.get("DCVIC_THIN_MIN_PIXELS", "16384"))   # full-resolution maps only (the 4-channel latent convs at 1/8 stay on the MFMA kernels)
 THIN_ENABLED = os.environ.get("DCVIC_THIN", "1") != "0"       # VALU kernels for the 3 -> 128 / 128 -> 3 layers (csrc/thin.hip)
 WINO44_MIN_BLOCKS = int(os.environ.get("DCVIC_WINO44_MIN_BLOCKS", "16"))   # workgroup tiles PER IMAGE below which F(2x2) / direct run
@@ -153,6 +154,7 @@ class ConvPlan:
     wino44 = False        # set by the owner: F(4x4,3x3) allowed too -- post-argmax layers only (3x the F(2x2) rounding error)
     _wino_pack = None
     _wino44_pack = None
+    last_gn_part = None   # (partial statistics [N, Cout, n_pt, 2], n_pt) written by the last call when gn_stats was asked AND the F(4x4) kernel ran
     _wino_ups_pack = None
 
     def __init__(self, weight: Tensor, bias: Optional[Tensor], kind: str = "conv", stride: int = 1,
@@ -281,7 +283,10 @@ class ConvPlan:
 
     def __call__(self, srcs, out: Optional[Tensor] = None, act: int = ACT_NONE, res: Optional[Tensor] = None,
                  affine: Optional[Tuple[Tensor, Tensor]] = None, out_hw: Optional[Tuple[int, int]] = None,
-                 init: Optional[Tensor] = None, use_bias: bool = True) -> Tensor:
+                 init: Optional[Tensor] = None, use_bias: bool = True, gn_stats: bool = False) -> Tensor:
+        """`gn_stats`: the caller's next op is a GroupNorm over exactly this output; when the launch runs on the F(4x4) kernel its epilogue
+        also writes the GroupNorm partial sums (self.last_gn_part, else None) and the GroupNorm skips its statistics pass."""
+        self.last_gn_part = None
         if isinstance(srcs, Tensor):
             srcs = [srcs]
         N, _, H, W = _chk4(srcs[0], "conv src0")
@@ -361,14 +366,25 @@ class ConvPlan:
             io.Hout, io.Wout = Hf, Wf
             io.osy = io.osx = 1
             io.ooy = io.oox = 0
+            part = None
+            if gn_stats and GN_FUSED_STATS:
+                n_pt = int(lib().dcvic_wino44_stats_tiles(H, W))
+                part = torch.empty((N, self.Cout, n_pt, 2), dtype=torch.float32, device=out.device)
+                self.last_gn_part = (part, n_pt)
+
+            def launch():
+                if part is None:
+                    check(lib().dcvic_conv3x3_wino44_f32(self.Cin, self.Cout, _p(self._wino44_pack), C.byref(io), st), "conv3x3_wino44")
+                else:
+                    check(lib().dcvic_conv3x3_wino44_stats_f32(self.Cin, self.Cout, _p(self._wino44_pack), C.byref(io), _p(part), st), "conv3x3_wino44_stats")
             if _EVENTS is not None:
                 e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
                 e0.record()
-                check(lib().dcvic_conv3x3_wino44_f32(self.Cin, self.Cout, _p(self._wino44_pack), C.byref(io), st), "conv3x3_wino44")
+                launch()
                 e1.record()
                 _EVENTS.append((9104, 2.0 * N * H * W * self.Cout * self.Cin * 9, e0, e1, (self.Cin, self.Cout, 9, 1, 0, H, W, N)))
             else:
-                check(lib().dcvic_conv3x3_wino44_f32(self.Cin, self.Cout, _p(self._wino44_pack), C.byref(io), st), "conv3x3_wino44")
+                launch()
             return out
         if self.wino and WINO_ENABLED and not self.ups_phases and not self.upsample and init is None and affine is None \
                 and (self.wino == "force" or self._wino_ok(srcs, N, H, W)) \
@@ -469,11 +485,19 @@ def attn_fused(qkv: Tensor, Cc: int, out: Optional[Tensor] = None, force_nw: int
 
 # ------------------------------------------------------------------------------------------- norms
 def groupnorm(x: Tensor, gamma: Tensor, beta: Tensor, groups: int = 32, eps: float = 1e-6, act: int = ACT_NONE,
-              out: Optional[Tensor] = None) -> Tensor:
+              out: Optional[Tensor] = None, part=None) -> Tensor:
+    """`part` = (partial statistics [N, C, n_pt, 2], n_pt) of exactly `x`, from the convolution that produced it (ConvPlan.last_gn_part)."""
     N, Cc, H, W = _chk4(x, "groupnorm x")
     if out is None:
         out = new(N, Cc, H, W, x)
     _chk4(out, "groupnorm out")
+    if part is not None:
+        pt, n_pt = part
+        if tuple(pt.shape) != (N, Cc, n_pt, 2) or not pt.is_contiguous():
+            raise ValueError(f"groupnorm: partial statistics {tuple(pt.shape)} do not belong to a {tuple(x.shape)} map")
+        check(lib().dcvic_groupnorm_part_f32(_p(x), C.c_longlong(_bs(x)), _p(out), C.c_longlong(_bs(out)), _p(gamma), _p(beta),
+                                             N, Cc, H * W, groups, C.c_float(eps), act, _p(pt), n_pt, _stream()), "groupnorm_part")
+        return out
     check(lib().dcvic_groupnorm_f32(_p(x), C.c_longlong(_bs(x)), _p(out), C.c_longlong(_bs(out)), _p(gamma), _p(beta),
                                     N, Cc, H * W, groups, C.c_float(eps), act, _stream()), "groupnorm")
     return out

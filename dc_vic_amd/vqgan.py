@@ -37,12 +37,17 @@ class ResnetBlock(nn.Module):
         if in_channels != out_channels:
             self.nin_shortcut = Conv2d(in_channels, out_channels, 1, 1, 0)
 
-    def forward(self, x: Tensor, out: Optional[Tensor] = None) -> Tensor:
-        h = self.norm1(x, act=ops.ACT_SWISH)
-        h = self.conv1(h)
-        h = self.norm2(h, act=ops.ACT_SWISH, out=h)
+    def forward(self, x: Tensor, out: Optional[Tensor] = None, in_part=None, want_part: bool = False) -> Tensor:
+        """`in_part`: GroupNorm partial statistics of `x` from the convolution that produced it (or None); `want_part`: the caller feeds
+        this block's output straight into another GroupNorm -- `self.out_part` then holds its statistics when conv2 ran on the F(4x4)
+        kernel (decoder side only: the encoder's convolutions never do, its GroupNorms keep their own fp64 pass and their bits)."""
+        h = self.norm1(x, act=ops.ACT_SWISH, part=in_part)
+        h = self.conv1(h, gn_stats=True)
+        h = self.norm2(h, act=ops.ACT_SWISH, out=h, part=self.conv1.take_gn_part())
         skip = self.nin_shortcut(x) if self.in_channels != self.out_channels else x
-        return self.conv2(h, res=skip, out=out)
+        y = self.conv2(h, res=skip, out=out, gn_stats=want_part)
+        self.out_part = self.conv2.take_gn_part()
+        return y
 
 
 class AttnBlock(nn.Module):
@@ -217,16 +222,22 @@ class Decoder(nn.Module):
         h = self.mid.block_1(h)
         h = self.mid.attn_1(h)
         h = self.mid.block_2(h)
+        part = None                                   # GroupNorm statistics of `h` from its producer, while `h` comes straight out of a ResnetBlock
         for i_level in reversed(range(self.num_resolutions)):
             for i_block in range(self.num_res_blocks + 1):
-                h = self.up[i_level].block[i_block](h)
-                if len(self.up[i_level].attn) > 0:
+                blk = self.up[i_level].block[i_block]
+                has_attn = len(self.up[i_level].attn) > 0
+                h = blk(h, in_part=part, want_part=not has_attn)
+                part = blk.out_part
+                if has_attn:
                     h = self.up[i_level].attn[i_block](h)
+                    part = None
             if i_level != 0:
                 h = self.up[i_level].upsample(h)
+                part = None
         if self.give_pre_end:
             return h
-        h = self.norm_out(h, act=ops.ACT_SWISH, out=h)
+        h = self.norm_out(h, act=ops.ACT_SWISH, out=h, part=part)
         return self.conv_out(h)
 
 

@@ -168,6 +168,12 @@ int dcvic_conv3x3_wino_ups_f32(int Cin, int Cout, const float* packed, const dcv
 size_t dcvic_wino44_packed_bytes(int Cin, int Cout);
 int dcvic_wino44_pack_f32(const float* w, float* packed, int Cin, int Cout, void* stream);
 int dcvic_conv3x3_wino44_f32(int Cin, int Cout, const float* packed, const dcvic_conv_io* io, void* stream);
+/* The same convolution, additionally writing the GroupNorm statistics of its output: gn_part[N][Cout][n_pt][2] = per (image, output
+ * channel, 16 x 32-pixel tile) the sum and the sum of squares of the values stored (n_pt = dcvic_wino44_stats_tiles(H, W)), so that the
+ * GroupNorm that follows (ldm Normalize, model.py:38-39, inside ResnetBlock model.py:117-133) need not read the map for its statistics:
+ * dcvic_groupnorm_part_f32.  Fixed summation order, no atomics. */
+int dcvic_wino44_stats_tiles(int H, int W);
+int dcvic_conv3x3_wino44_stats_f32(int Cin, int Cout, const float* packed, const dcvic_conv_io* io, float* gn_part, void* stream);
 /* Conv2d(k3, s1, p1) with Cout <= 4 (Cin % 8 == 0) or Cin <= 4 (csrc/thin.hip): the VQGAN decoder's conv_out (128 -> 3,
  * ldm/modules/diffusionmodules/model.py:553-557) and the VQGAN encoder's conv_in (3 -> 128, model.py:388-392).  HBM-bound fp32
  * fmaf chains on the vector ALU in exactly the reduction order of dcvic_conv2d_f32, hence BIT-IDENTICAL to it; unpacked weights
@@ -203,6 +209,11 @@ int dcvic_attn_fused_f32(const float* q, const float* k, const float* v, long lo
  * femasr_layers.py:20-21, codeformer_layers.py:14-15.  Two-pass fp32 statistics per (n, group). */
 int dcvic_groupnorm_f32(const float* x, long long x_bs, float* y, long long y_bs, const float* gamma,
                         const float* beta, int N, int C, int HW, int groups, float eps, int act, void* stream);
+/* The same GroupNorm with the statistics pass replaced by the producer's partial sums (dcvic_conv3x3_wino44_stats_f32): part[N][C][n_pt][2],
+ * added per (n, group) in fp64 in a fixed order -- one read + one write of the map instead of two reads + one write. */
+int dcvic_groupnorm_part_f32(const float* x, long long x_bs, float* y, long long y_bs, const float* gamma,
+                             const float* beta, int N, int C, int HW, int groups, float eps, int act,
+                             const float* part, int n_pt, void* stream);
 /* LayerNorm over the channel axis of an NCHW map (== nn.LayerNorm(C) on the [B, HW, C] token view,
  * swinir_layers.py:190,199), eps 1e-5. */
 int dcvic_layernorm_c_f32(const float* x, float* y, const float* gamma, const float* beta, int N, int C,

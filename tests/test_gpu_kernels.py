@@ -974,3 +974,40 @@ def test_thin_conv_bit_identical_to_the_mfma_kernels(dev, case):
     y1 = plan(x[:1].contiguous(), act=act, res=None if r is None else r[:1].contiguous())
     ops.THIN_MIN_PIXELS = old_min
     assert torch.equal(y1, y_thin[:1])                            # batch-invariant
+
+
+def test_groupnorm_statistics_from_the_wino44_epilogue(dev):
+    """the F(4x4) convolution's epilogue writes per (image, channel, pixel tile) partial sums of exactly the values it
+    stores (bias, LeakyReLU and residual included); dcvic_groupnorm_part_f32 adds them in fp64 and skips its own statistics pass.
+    Checked: the partials against fp64 sums of the stored map (ragged size: partial tiles, Cout not a multiple of 64), and the
+    GroupNorm + swish output against the two-pass kernel on the same map (1e-6 relative: fp32 tile sums instead of one fp64 sum)."""
+    from dc_vic_amd import ops
+    N, Cin, Cout, H, W = 3, 64, 160, 40, 72
+    x = rnd(N, Cin, H, W, seed=95).to(dev)
+    w = rnd(Cout, Cin, 3, 3, seed=96, scale=(Cin * 9) ** -0.5).to(dev)
+    b = rnd(Cout, seed=97, scale=0.5).to(dev)
+    r = rnd(N, Cout, H, W, seed=98).to(dev)
+    plan = ops.ConvPlan(w, b, "conv", pad=(1, 1))
+    plan.wino = plan.wino44 = "force"
+    y = plan(x, act=ops.ACT_LRELU02, res=r, gn_stats=True)
+    part, n_pt = plan.last_gn_part
+    assert n_pt == 3 * 3 and tuple(part.shape) == (N, Cout, n_pt, 2)
+    yd = y.double()
+    S = part[..., 0].double().sum(-1).cpu(); Q = part[..., 1].double().sum(-1).cpu()
+    assert float((S - yd.sum((2, 3)).cpu()).abs().max()) < 1e-3 * float(yd.abs().sum((2, 3)).max()) * 1e-3
+    assert float((Q - (yd * yd).sum((2, 3)).cpu()).abs().max()) < 1e-6 * float((yd * yd).sum((2, 3)).max())
+    # one tile alone: rows 32..39 of the map (the ragged last tile row), columns 64..71
+    t = yd[:, :, 32:40, 64:72]
+    assert float((part[:, :, 8, 0].double().cpu() - t.sum((2, 3)).cpu()).abs().max()) < 1e-4
+    g, be = (rnd(Cout, seed=99, scale=1.0) + 1.0).to(dev), rnd(Cout, seed=100, scale=0.3).to(dev)
+    a = ops.groupnorm(y, g, be, 32, 1e-6, ops.ACT_SWISH)
+    bq = ops.groupnorm(y, g, be, 32, 1e-6, ops.ACT_SWISH, part=(part, n_pt))
+    assert float((a - bq).abs().max()) < 2e-6 * float(a.abs().max())
+    # no statistics asked / not an F(4x4) launch: nothing handed over
+    plan(x, act=ops.ACT_LRELU02, res=r)
+    assert plan.last_gn_part is None
+    p2 = ops.ConvPlan(w, b, "conv", pad=(1, 1)); p2.wino = "force"
+    p2(x, gn_stats=True)
+    assert p2.last_gn_part is None
+    with pytest.raises(ValueError):
+        ops.groupnorm(y[:, :128].contiguous(), g[:128], be[:128], 32, 1e-6, ops.ACT_SWISH, part=(part, n_pt))
