@@ -100,7 +100,13 @@ def main():
     from dc_vic_amd.parallel import pin_rank_cpus
     cpus = pin_rank_cpus()            # the ranks of a node share its cores: each takes its slice (rANS threads)
     dist = None
+    saved_stdout = None
     if world > 1 or "TORCHELASTIC_RUN_ID" in os.environ or os.environ.get("DCVIC_FORCE_DIST") == "1":
+        # RCCL prints a version banner on STDOUT when its first communicator comes up; the contract is ONE JSON line there.  Point fd 1
+        # at stderr until the result line is printed (every rank: only rank 0 ever writes to stdout).
+        sys.stdout.flush()
+        saved_stdout = os.dup(1)
+        os.dup2(2, 1)
         # launched by torch.distributed.run: take the collective path even at world size 1 (same code as N > 1)
         import torch.distributed as dist_
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -128,6 +134,8 @@ def main():
         imgs, _, _ = model.decompress_batch(r["string_lists"])
         real_bits = np.array([8.0 * sum(len(s) for s in sl) + 32 * 3 for sl in r["string_lists"]])   # + 3 uint32 length prefixes
         table = np.stack([real_bits, r["pred_y_bit"] + r["pred_z_bit"]], axis=1)
+        if dist is not None:
+            torch.cuda.synchronize(dev)                   # (so that the figure below is the collective, not the tail of the decoder kernels)
         tg = time.perf_counter()
         table = gather_rate_table(table, dist, dev)       # the only collective: a few KB over RCCL
         gather_s[0] += time.perf_counter() - tg
@@ -259,6 +267,9 @@ def main():
             out["cpu_baseline"] = cpu_baseline(sd, a.quality)
         else:
             out["cpu_baseline"] = None
+        if saved_stdout is not None:
+            sys.stdout.flush()
+            os.dup2(saved_stdout, 1)                      # the real stdout back for the one result line
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()
