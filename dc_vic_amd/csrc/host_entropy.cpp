@@ -17,6 +17,10 @@
 
 #include <cmath>
 #include <thread>
+#include <atomic>
+#include <condition_variable>
+#include <functional>
+#include <mutex>
 #include <vector>
 
 #include "common.h"
@@ -205,16 +209,74 @@ int decode_one(const dcvic_cdf_tables& T, dcvic_rans_decoder& d, const int32_t* 
     return DCVIC_OK;
 }
 
+// Persistent worker pool (one per process, grown on demand).  The decoder calls parallel_for six times per batch for ~0.3 ms of work
+// each: spawning std::threads per call (round 2) cost as much as the decode itself beyond 16 threads.  Tasks are handed out through an
+// atomic counter; the calling thread works too; at most `threads` threads touch a call.  Calls are serialised by `run_mutex` (two Python
+// threads coding at once take turns).
+class WorkerPool {
+public:
+    static WorkerPool& get() { static WorkerPool p; return p; }
+    template <typename F>
+    void run(int n, int threads, F&& f) {
+        std::lock_guard<std::mutex> serial(run_mutex);
+        ensure(threads - 1);
+        std::function<void(int)> fn = [&](int i) { f(i); };
+        {
+            std::lock_guard<std::mutex> lk(m);
+            task = &fn; n_tasks = n; next.store(0); done = 0; helpers = threads - 1; ++generation;
+        }
+        cv_work.notify_all();
+        work(fn, n);
+        std::unique_lock<std::mutex> lk(m);
+        cv_done.wait(lk, [&] { return done == n_tasks && busy == 0; });
+        task = nullptr;
+    }
+    ~WorkerPool() {
+        { std::lock_guard<std::mutex> lk(m); stop = true; ++generation; }
+        cv_work.notify_all();
+        for (auto& t : workers) t.join();
+    }
+private:
+    void work(const std::function<void(int)>& fn, int n) {
+        int finished = 0;
+        for (int i; (i = next.fetch_add(1)) < n;) { fn(i); ++finished; }
+        if (finished) { std::lock_guard<std::mutex> lk(m); done += finished; if (done == n_tasks) cv_done.notify_all(); }
+    }
+    void ensure(int count) {
+        while ((int)workers.size() < count) {
+            const int id = (int)workers.size();
+            workers.emplace_back([this, id]() {
+                unsigned long long seen = 0;
+                for (;;) {
+                    const std::function<void(int)>* fn; int n;
+                    {
+                        std::unique_lock<std::mutex> lk(m);
+                        cv_work.wait(lk, [&] { return stop || (generation != seen && id < helpers && task); });
+                        if (stop) return;
+                        seen = generation; fn = task; n = n_tasks; ++busy;
+                    }
+                    work(*fn, n);
+                    { std::lock_guard<std::mutex> lk(m); --busy; if (done == n_tasks && busy == 0) cv_done.notify_all(); }
+                }
+            });
+        }
+    }
+    std::vector<std::thread> workers;
+    std::mutex m, run_mutex;
+    std::condition_variable cv_work, cv_done;
+    const std::function<void(int)>* task = nullptr;
+    std::atomic<int> next{0};
+    int n_tasks = 0, done = 0, helpers = 0, busy = 0;
+    unsigned long long generation = 0;
+    bool stop = false;
+};
+
 template <typename F>
 void parallel_for(int n, int threads, F&& f) {
     if (threads < 1) threads = 1;
     if (threads > n) threads = n;
     if (threads == 1) { for (int i = 0; i < n; ++i) f(i); return; }
-    std::vector<std::thread> pool;
-    pool.reserve(threads);
-    for (int t = 0; t < threads; ++t)
-        pool.emplace_back([&, t]() { for (int i = t; i < n; i += threads) f(i); });
-    for (auto& th : pool) th.join();
+    WorkerPool::get().run(n, threads, f);
 }
 
 }  // namespace

@@ -39,13 +39,14 @@ def get_scale_table(min_: float = SCALES_MIN, max_: float = SCALES_MAX, levels: 
 
 
 def host_threads() -> int:
-    """rANS coder threads of this rank: min(16, its share of the host cores) -- affinity // LOCAL_WORLD_SIZE, so the
-    N ranks of a node together stay within the machine (DCVIC_HOST_THREADS overrides)."""
+    """rANS coder threads of this rank: min(32, its share of the host cores) -- affinity // LOCAL_WORLD_SIZE, so the
+    N ranks of a node together stay within the machine (DCVIC_HOST_THREADS overrides).  32 = one per image of the benchmark batch:
+    the streams are independent and the coder runs on a persistent worker pool (csrc/host_entropy.cpp)."""
     env = os.environ.get("DCVIC_HOST_THREADS")
     if env:
         return max(1, int(env))
     from .parallel import host_core_budget
-    return max(1, min(16, host_core_budget()))
+    return max(1, min(32, host_core_budget()))
 
 
 def _pmf_to_cdf(pmf: Tensor, tail_mass: Tensor, pmf_length: Tensor, max_length: int) -> np.ndarray:

@@ -98,3 +98,38 @@ def test_rans_empty_and_corrupt(gc_tables):
     with pytest.raises(DcvicError):
         dec.decode(idx)
     dec.close()
+
+
+def test_worker_pool_many_calls_and_thread_counts(gc_tables):
+    """The coder's persistent worker pool (csrc/host_entropy.cpp): hundreds of back-to-back encode / incremental-decode calls with
+    changing thread counts and stream counts give the streams and symbols of the single-threaded coder, from two Python threads at once
+    as well (calls are serialised inside the library)."""
+    import threading
+    T = gc_tables.tables()
+    errors = []
+
+    def worker(seed):
+        r = np.random.RandomState(seed)
+        for it in range(60):
+            ns, n = int(r.randint(1, 40)), int(r.randint(1, 600))
+            idx = r.randint(0, 64, (ns, n)).astype(np.int32)
+            sym = r.randint(-30, 31, (ns, n)).astype(np.int32)
+            sym[r.rand(ns, n) < 0.01] = 5000                       # some out of range: bypass escapes
+            ref = T.encode(sym, idx, threads=1)
+            thr = int(r.choice([2, 3, 8, 16, 32, 64]))
+            got = T.encode(sym, idx, threads=thr)
+            if got != ref:
+                errors.append(("encode", seed, it, thr)); return
+            dec = T.decoders(got)
+            try:
+                half = n // 2
+                a = dec.decode(np.ascontiguousarray(idx[:, :half]), threads=thr) if half else np.zeros((ns, 0), np.int32)
+                b = dec.decode(np.ascontiguousarray(idx[:, half:]), threads=int(r.choice([1, 5, 32])))
+            finally:
+                dec.close()
+            if not (np.array_equal(a, sym[:, :half]) and np.array_equal(b, sym[:, half:])):
+                errors.append(("decode", seed, it, thr)); return
+
+    ts = [threading.Thread(target=worker, args=(s_,)) for s_ in (1, 2)]
+    [t.start() for t in ts]; [t.join() for t in ts]
+    assert not errors, errors

@@ -67,7 +67,7 @@ def test_gather_rate_table_world2(tmp_path):
     share = max(1, n // 2)
     for b in (b0, b1):
         assert b["budget_unpinned"] == share
-        assert b["threads_unpinned"] == b["threads_pinned"] == min(16, share)
+        assert b["threads_unpinned"] == b["threads_pinned"] == min(32, share)
         assert b["io_unpinned"] == b["io_pinned"] == min(8, share)
         assert len(b["cpus"]) == share
     if n >= 2:
