@@ -46,6 +46,7 @@ def parse():
     p.add_argument("--width", type=int, default=256)
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-kernel-events", action="store_true", help="skip the per-launch HIP events (roofline becomes null)")
+    p.add_argument("--event-steps", type=int, default=2, help="eager steps with per-launch HIP events behind the timed region (roofline)")
     return p.parse_args()
 
 
@@ -151,13 +152,18 @@ def main():
         if rank == 0:
             print(f"[bench] {msg}", file=sys.stderr, flush=True)
 
+    # model setup (untimed, before the W warm-up steps): lazy weight packing on the first pass, hipGraph capture of the encoder / decoder
+    # networks on the second (comp_model._GraphCache captures a shape the second time it sees it)
+    t_s = time.perf_counter()
+    for _ in range(2):
+        step()
+    sync()
+    log(f"model set up (weight packs, hipGraph capture) in {time.perf_counter() - t_s:.2f}s")
     t_w = time.perf_counter()
     for _ in range(a.warmup):
         step()
     sync()
-    log(f"model ready, {a.warmup} warm-up step(s) in {time.perf_counter() - t_w:.2f}s")
-    if not a.no_kernel_events:
-        ops.kernel_events_start()
+    log(f"{a.warmup} warm-up step(s) in {time.perf_counter() - t_w:.2f}s")
     gather_s[0] = 0.0
     t0 = time.perf_counter()
     for _ in range(a.steps):
@@ -167,7 +173,20 @@ def main():
     sync()
     dt = time.perf_counter() - t0
     log(f"{a.steps} timed step(s) in {dt:.2f}s")
-    ev = ops.kernel_events_stop() if not a.no_kernel_events else None
+    # Per-launch HIP events for the roofline.  The timed steps replay the two network segments as hipGraphs, which cannot carry
+    # per-launch events, so the SAME step is run `--event-steps` more times right behind the timed region with the events on (eager
+    # launches of the same kernels with the same arguments, on the stream they run on); rocprofv3 of this command reports the same
+    # average durations (profiles/).  dt_ev = wall time of those steps, the denominator of the per-kernel time shares.
+    ev, dt_ev, gather_keep = None, None, gather_s[0]
+    if not a.no_kernel_events:
+        ops.kernel_events_start()
+        t_e = time.perf_counter()
+        for _ in range(max(1, a.event_steps)):
+            step()
+        sync()
+        dt_ev = time.perf_counter() - t_e
+        ev = ops.kernel_events_stop()
+        gather_s[0] = gather_keep
     if ev and rank == 0 and os.environ.get("DCVIC_BENCH_DETAIL"):
         print(ops.shape_stats_report(), file=sys.stderr, flush=True)
 
@@ -248,7 +267,7 @@ def main():
             alg = k["flops"] / k["time_s"] / 1e12
             exe = k["exec_flops"] / k["time_s"] / 1e12
             tot_exec = sum(d["exec_flops"] for d in ev.values())
-            out["end_to_end_executed_conv_mfma_frac_of_f32_peak"] = tot_exec / dt / 1e12 / PEAK_F32_MFMA_TFLOPS
+            out["end_to_end_executed_conv_mfma_frac_of_f32_peak"] = tot_exec / max(1, a.event_steps) * a.steps / dt / 1e12 / PEAK_F32_MFMA_TFLOPS
             out["roofline"] = {"bound": "mfma", "kernel": k["kernel"], "achieved": exe,
                                "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": exe / PEAK_F32_MFMA_TFLOPS,
                                "algorithmic_tflops": alg, "executed_per_algorithmic_flop": k["exec_flops"] / k["flops"],
@@ -257,10 +276,12 @@ def main():
                                "traffic": traffic, "traffic_source": traffic_src, "launches": k["launches"], "avg_launch_us": 1e6 * k["time_s"] / k["launches"],
                                "gflop_per_launch": k["flops"] / k["launches"] / 1e9,
                                "executed_gflop_per_launch": k["exec_flops"] / k["launches"] / 1e9,
-                               "share_of_step_time": k["time_s"] / dt,
+                               "share_of_step_time": k["time_s"] / dt_ev,
+                               "measured_over": f"{max(1, a.event_steps)} eager step(s) with per-launch HIP events right behind the timed region "
+                                                "(the timed steps replay hipGraphs, which cannot carry per-launch events); same kernels, same arguments",
                                "all_conv_kernels": {n: {"tflops": d["exec_flops"] / d["time_s"] / 1e12,
                                                         "algorithmic_tflops": d["flops"] / d["time_s"] / 1e12, "launches": d["launches"],
-                                                        "time_share": d["time_s"] / dt} for n, d in ev.items()}}
+                                                        "time_share": d["time_s"] / dt_ev} for n, d in ev.items()}}
         else:
             out["roofline"] = None
         if world == 1 and not a.no_cpu_baseline:

@@ -49,23 +49,29 @@ TILE_BATCH = max(1, int(os.environ.get("DCVIC_TILE_BATCH", "32")))
 
 
 class _GraphCache:
-    """hipGraph replay of a pure-device network segment (no host sync inside) for small batches, where a 256x256 image is
-    ~1 500 kernel launches of a few microseconds each and the Python/ctypes launcher, not the GPU, sets the latency.
-    A segment is captured once per (segment, input shapes, conditioning) on torch's capture stream -- the C-ABI kernels
-    launch on torch's current stream, so they are recorded like any other work -- and replayed afterwards; inputs are
-    copied into the graph's static buffers, outputs are the graph's static tensors (valid until the next replay).
-    Captures that fail (unsupported call inside the segment) fall back to the eager path for good."""
+    """hipGraph replay of a pure-device network segment (no host sync inside): the encoder networks of `compress_batch` and the decoder
+    networks of `decompress_batch` are ~640 kernel launches per 32-image batch, a third of them shorter than the ~10 us the Python /
+    ctypes launcher needs per launch, so the GPU idles between them (6 ms of a 166-ms step by the rocprofv3 trace).  A segment is captured
+    on torch's capture stream -- the C-ABI kernels launch on torch's current stream, so they are recorded like any other work -- and
+    replayed afterwards; inputs are copied into the graph's static buffers, outputs are the graph's static tensors (valid until the next
+    replay).  Same kernels, same arguments: results are bit-identical to the eager path (tested).
+    Policy: a (segment, input shapes, conditioning) key is captured the SECOND time it is seen (`capture_after`; a folder of images that
+    all differ in size stays eager: a capture costs two extra passes), up to `max_pixels` per call and `max_entries` graphs (LRU).
+    Captures that fail (unsupported call inside the segment) fall back to the eager path for good.  On by default since round 3
+    (measured 193 -> 200 images/s at batch 32); `DCVIC_GRAPHS=0` switches it off.  Per-launch HIP events (bench.py's roofline steps,
+    ops.kernel_events_start) and the stage hook bypass it."""
 
-    def __init__(self, max_entries: int = 6):
+    def __init__(self, max_entries: int = 4):
         self.entries: "OrderedDict" = OrderedDict()
-        self.max_entries = max_entries
-        # opt-in (DCVIC_GRAPHS=1): measured on MI355X, N=1 at 256x256 is NOT launch-bound -- the ~900 kernels of a
-        # compress+decompress keep the GPU busy for 54 of 54 ms (one 32x32 MFMA chain per SIMD), so replay buys nothing
-        self.disabled = os.environ.get("DCVIC_GRAPHS", "0") != "1"
-        self.max_pixels = int(os.environ.get("DCVIC_GRAPH_MAX_PIXELS", str(1 << 20)))
+        self.seen: Dict = {}
+        self.max_entries = int(os.environ.get("DCVIC_GRAPH_MAX_ENTRIES", str(max_entries)))
+        self.disabled = os.environ.get("DCVIC_GRAPHS", "1") == "0"
+        self.max_pixels = int(os.environ.get("DCVIC_GRAPH_MAX_PIXELS", str(4 << 20)))      # 32 x 256^2 = 2.1 M, 8 x 512x768 = 3.1 M
+        self.capture_after = max(1, int(os.environ.get("DCVIC_GRAPH_CAPTURE_AFTER", "2")))
 
     def clear(self):
         self.entries.clear()
+        self.seen.clear()
 
     def usable(self, n_pixels: int) -> bool:
         return (not self.disabled) and n_pixels <= self.max_pixels and ops._EVENTS is None and STAGE_HOOK is None
@@ -73,6 +79,12 @@ class _GraphCache:
     def run(self, key, fn, inputs: Sequence[Tensor], keep=None):
         ent = self.entries.get(key)
         if ent is None:
+            n = self.seen.get(key, 0) + 1
+            if len(self.seen) > 256:
+                self.seen.clear()
+            self.seen[key] = n
+            if n < self.capture_after:
+                return fn(*inputs)                     # first sighting of this shape: eager
             static_in = [torch.empty_like(t) for t in inputs]
             for s_, t in zip(static_in, inputs):
                 s_.copy_(t)
@@ -88,7 +100,8 @@ class _GraphCache:
             except Exception as e:                     # noqa: BLE001 -- any capture failure means "stay eager"
                 self.disabled = True
                 torch.cuda.synchronize()
-                print(f"[dc_vic_amd] hipGraph capture disabled: {type(e).__name__}: {e}", flush=True)
+                import sys
+                print(f"[dc_vic_amd] hipGraph capture disabled: {type(e).__name__}: {e}", file=sys.stderr, flush=True)
                 if os.environ.get("DCVIC_GRAPH_DEBUG"):
                     import traceback
                     traceback.print_exc()

@@ -385,10 +385,19 @@ def test_charm_split_and_streams_bit_identical(model, monkeypatch):
 
 
 def test_hipgraph_replay_identical_to_eager(model):
-    """Opt-in (DCVIC_GRAPHS=1): small batches replay the encoder / decoder networks as captured hipGraphs.  Same
-    kernels, same arguments: bytes and reconstructions equal the eager path's, across repeated replays and a second shape."""
+    """The encoder / decoder networks replay as captured hipGraphs (default since round 3, DCVIC_GRAPHS=0 switches it off).  Same
+    kernels, same arguments: bytes and reconstructions equal the eager path's, across repeated replays and a second shape; a shape is
+    captured the SECOND time it is seen (capture_after = 2)."""
     g = model._graphs
-    was = g.disabled
+    was, was_after = g.disabled, g.capture_after
+    assert was_after == 2 and not was
+    g.clear()
+    x0 = img((1, 3, 64, 64), 109)
+    model.compress_batch(x0, 0)
+    assert not g.entries                               # first sighting: eager
+    model.compress_batch(x0, 0)
+    assert [k[0] for k in g.entries] == ["enc"]        # second: captured and replayed
+    g.capture_after = 1
     try:
         for shape, q in (((1, 3, 256, 256), 0), ((2, 3, 128, 192), 3)):
             x1, x2 = img(shape, 107), img(shape, 108)
@@ -409,7 +418,8 @@ def test_hipgraph_replay_identical_to_eager(model):
             kinds = sorted(k[0] for k in g.entries)
             assert "dec" in kinds and "enc" in kinds, kinds
     finally:
-        g.disabled = was
+        g.disabled, g.capture_after = was, was_after
+        g.clear()
 
 
 def test_fused_groupnorm_statistics_change_only_the_decoder_at_1e6(model):
@@ -417,15 +427,18 @@ def test_fused_groupnorm_statistics_change_only_the_decoder_at_1e6(model):
     untouched bit for bit, the reconstruction moves by < 5e-5 (measured 1.4e-5) against the two-pass GroupNorm (ops.GN_FUSED_STATS = False)."""
     from dc_vic_amd import ops
     x = img((2, 3, 256, 256), 120)
-    r1 = model.compress_batch(x, 1)
-    i1, z1, y1 = model.decompress_batch(r1["string_lists"])
+    g_was = model._graphs.disabled
+    model._graphs.disabled = True                      # (a captured decoder graph would freeze whichever variant it recorded)
     old = ops.GN_FUSED_STATS
-    ops.GN_FUSED_STATS = False
     try:
+        r1 = model.compress_batch(x, 1)
+        i1, z1, y1 = model.decompress_batch(r1["string_lists"])
+        ops.GN_FUSED_STATS = False
         r0 = model.compress_batch(x, 1)
         i0, z0, y0 = model.decompress_batch(r0["string_lists"])
     finally:
         ops.GN_FUSED_STATS = old
+        model._graphs.disabled = g_was
     assert r0["string_lists"] == r1["string_lists"] and torch.equal(y0, y1) and torch.equal(z0, z1)
     d = float((i0 - i1).abs().max())
     assert 0.0 < d < 5e-5, d              # measured 1.4e-5 (24 GroupNorms with fp32 tile sums); > 0: the fused path really ran
