@@ -89,11 +89,15 @@ class _GraphCache:
             for s_, t in zip(static_in, inputs):
                 s_.copy_(t)
             try:
-                side = torch.cuda.Stream()
-                side.wait_stream(torch.cuda.current_stream())
-                with torch.cuda.stream(side):          # warm-up: lazy weight packs, function attributes, caches
-                    fn(*static_in)
-                torch.cuda.current_stream().wait_stream(side)
+                if n == 1:
+                    # capture at first sight (capture_after = 1): a warm-up pass for the lazy weight packs, function attributes and
+                    # caches.  From the second sighting on the eager pass(es) already did that: the capture itself executes nothing,
+                    # so capturing costs one launcher pass (~10 ms of host time), not a network pass
+                    side = torch.cuda.Stream()
+                    side.wait_stream(torch.cuda.current_stream())
+                    with torch.cuda.stream(side):
+                        fn(*static_in)
+                    torch.cuda.current_stream().wait_stream(side)
                 graph = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(graph):
                     out = fn(*static_in)

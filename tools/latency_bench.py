@@ -13,7 +13,9 @@ def main():
     for name, shape in (("256x256", (1, 3, 256, 256)), ("kodak_512x768", (1, 3, 512, 768)), ("2k_1280x2048_tiled", (1, 3, 1280, 2048))):
         g = torch.Generator().manual_seed(3)
         x = (torch.rand(shape, generator=g) * 2 - 1).to("cuda:0")
-        r = m.compress(x, 0); m.decompress(r["string_list"]); torch.cuda.synchronize()
+        for _ in range(3):          # lazy weight packs, then hipGraph capture (second sighting), then steady state
+            r = m.compress(x, 0); m.decompress(r["string_list"])
+        torch.cuda.synchronize()
         reps = 5 if shape[2] <= 512 else 2
         t0 = time.perf_counter()
         for _ in range(reps):
