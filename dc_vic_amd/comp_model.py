@@ -207,6 +207,8 @@ class BaseModel(nn.Module):
         super().__init__()
         self.opt = opt
         self.device = _get(opt, "device", "cuda:0")
+        if str(self.device) == "cuda" and torch.cuda.is_available():
+            self.device = f"cuda:{torch.cuda.current_device()}"          # the reference's `-d cuda`: the current device
         if str(self.device).startswith("cuda") and torch.cuda.is_available():
             # the C-ABI kernels launch on the current device's current stream (`-d cuda:1` must make cuda:1 current)
             torch.cuda.set_device(torch.device(self.device))

@@ -83,6 +83,8 @@ def main():
 
     overrides = {k: v for k, v in vars(args).items() if k not in ("batch_size", "synthetic_weights", "io_workers", "gpus")}
     overrides["device"] = device
+    if device == "cuda":
+        device = overrides["device"] = f"cuda:{torch.cuda.current_device()}"      # the reference's `-d cuda`
     if device.startswith("cuda"):
         torch.cuda.set_device(torch.device(device))      # `-d cuda:1` makes cuda:1 the current device (kernels launch there)
     overrides["is_train"] = False
@@ -123,10 +125,22 @@ def main():
             chunks.append(idxs[s:s + max(1, args.batch_size)])
     writer = AsyncWriter(args.io_workers or None)
     loader = BatchPrefetcher([[img_path_list[i] for i in c] for c in chunks], device, workers=args.io_workers or None)
+    timing = {"wait_png_decode": 0.0, "compress": 0.0, "bin_io_csv_rows": 0.0, "decompress": 0.0, "d2h_submit_png": 0.0, "drain_png_encode": 0.0}
+    import time
+    def lap(key, t0):
+        if device.startswith("cuda") and os.environ.get("DCVIC_CLI_TIMING"):
+            torch.cuda.synchronize()
+        timing[key] += time.time() - t0
+        return time.time()
     try:
-        for chunk, (_, x) in zip(chunks, loader):
+        it = iter(loader)
+        for chunk in chunks:
+            t = time.time()
+            _, x = next(it)
+            t = lap("wait_png_decode", t)
             H, W = sizes[chunk[0]]
             out = model.compress_batch(x, args.quality)
+            t = lap("compress", t)
             bins = []
             for j, i in enumerate(chunk):
                 name = os.path.basename(img_path_list[i])
@@ -141,12 +155,19 @@ def main():
                            float(out["pred_z_bpp"][j] + out["pred_y_bpp"][j]), H * W]
             if args.decompress:
                 loaded = [load_byte_strings(b) for b in bins]
+                t = lap("bin_io_csv_rows", t)
                 _, _, _, u8 = model.decompress_batch(loaded, want_u8=True)
+                t = lap("decompress", t)
                 u8 = u8.cpu().numpy()
                 for j, i in enumerate(chunk):
                     writer.submit(encode_png_u8, os.path.join(args.save_dir, os.path.basename(img_path_list[i])), u8[j].copy())
+                t = lap("d2h_submit_png", t)
     finally:
+        t = time.time()
         writer.close()
+        timing["drain_png_encode"] = time.time() - t
+    if os.environ.get("DCVIC_CLI_TIMING"):
+        print(f"[compress] rank {rank} seconds: " + json.dumps({k: round(v, 2) for k, v in timing.items()}), file=sys.stderr)
 
     # gather the per-image rows (RCCL all_gather of a small fp64 table) and write the summary on rank 0
     local = np.array([[float(i)] + rows[i] for i in sorted(rows)], dtype=np.float64).reshape(-1, 11)

@@ -25,7 +25,7 @@ def test_cli_compress_decompress(tmp_path):
         Image.fromarray(im).save(img_dir / name)
     cmd = [sys.executable, os.path.join(ROOT, "scripts", "compress.py"), "--config_path", os.path.join(ROOT, "config", "dc_vic_synthetic.yaml"),
            "--model_path", "unused.pth.tar", "--img_dir", str(img_dir), "--save_dir", str(save_dir), "-q", "2", "--decompress",
-           "-d", "cuda:0", "--synthetic_weights", "--batch_size", "2"]
+           "-d", "cuda", "--synthetic_weights", "--batch_size", "2"]
     subprocess.check_call(cmd, cwd=ROOT)
     import pandas as pd
     df = pd.read_csv(save_dir / "_bitrates.csv", index_col=0)
