@@ -22,7 +22,8 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wno-unused-val
 
 # per-file extras.  wino.hip: hipcc's SLP vectoriser packs the input transform's adds into v_pk_add_f32, which costs MFMA issue
 # time beside the matrix pipe (MI355X_MICROARCH "packed f32 VALU ... an anti-lever beside MFMAs")
-EXTRA_FLAGS = {"wino.hip": ["-fno-slp-vectorize"], "wino44.hip": ["-fno-slp-vectorize"]}
+# thin.hip: the packed form of its fmaf chains needs a v_mov per misaligned register pair (491 of them in thin_cout_kernel<3>)
+EXTRA_FLAGS = {"wino.hip": ["-fno-slp-vectorize"], "wino44.hip": ["-fno-slp-vectorize"], "thin.hip": ["-fno-slp-vectorize"]}
 
 
 def _hipcc() -> str:

@@ -53,12 +53,20 @@ __global__ __launch_bounds__(512) void groupnorm_kernel(const float* __restrict_
         const float2* pp = reinterpret_cast<const float2*>(part) + ((long long)n * C + (long long)g * cg) * n_pt;
         for (int i = threadIdx.x; i < cg * n_pt; i += blockDim.x) { const float2 v = pp[i]; s += (double)v.x; q += (double)v.y; }
     } else if (vec) {
+        // four 16-byte loads in flight per thread (one per iteration left half of the HBM bandwidth unused: ~32 KiB in flight per CU);
+        // the additions keep the one-accumulator order i = tid, tid + B, tid + 2B, ... of the plain loop, so the sums are the same bits
         const float4* x4 = reinterpret_cast<const float4*>(xp);
-        for (long long i = threadIdx.x; i < len / 4; i += blockDim.x) {
-            const float4 v = x4[i];
+        const long long n4 = len / 4, B = blockDim.x;
+        auto acc = [&](const float4 v) {
             s += ((double)v.x + (double)v.y) + ((double)v.z + (double)v.w);
             q += ((double)v.x * v.x + (double)v.y * v.y) + ((double)v.z * v.z + (double)v.w * v.w);
+        };
+        long long i = threadIdx.x;
+        for (; i + 3 * B < n4; i += 4 * B) {
+            const float4 v0 = x4[i], v1 = x4[i + B], v2 = x4[i + 2 * B], v3 = x4[i + 3 * B];
+            acc(v0); acc(v1); acc(v2); acc(v3);
         }
+        for (; i < n4; i += B) acc(x4[i]);
     } else {
         for (long long i = threadIdx.x; i < len; i += blockDim.x) { const double v = xp[i]; s += v; q += v * v; }
     }
@@ -71,16 +79,27 @@ __global__ __launch_bounds__(512) void groupnorm_kernel(const float* __restrict_
         const float4* x4 = reinterpret_cast<const float4*>(xp);
         float4* y4 = reinterpret_cast<float4*>(yp);
         const int hw4 = HW / 4;
-        for (long long i = threadIdx.x; i < len / 4; i += blockDim.x) {
-            const int c = g * cg + (int)(i / hw4);
-            const float ga = gamma[c], be = beta[c];
-            float4 v = x4[i];
+        const long long n4 = len / 4;
+        const int B = blockDim.x;
+        // the channel of element i advances incrementally (no 64-bit division per element); four loads in flight per thread
+        int c = (int)threadIdx.x / hw4, j = (int)threadIdx.x - c * hw4;
+        const int sc = B / hw4, sj = B - sc * hw4;
+        auto put = [&](long long i, float4 v, int cc) {
+            const float ga = gamma[g * cg + cc], be = beta[g * cg + cc];
             v.x = dcvic_act((v.x - mean) * rstd * ga + be, act);
             v.y = dcvic_act((v.y - mean) * rstd * ga + be, act);
             v.z = dcvic_act((v.z - mean) * rstd * ga + be, act);
             v.w = dcvic_act((v.w - mean) * rstd * ga + be, act);
             y4[i] = v;
+        };
+        auto step = [&]() { c += sc; j += sj; if (j >= hw4) { j -= hw4; ++c; } };
+        long long i = threadIdx.x;
+        for (; i + 3LL * B < n4; i += 4LL * B) {
+            const float4 v0 = x4[i], v1 = x4[i + B], v2 = x4[i + 2LL * B], v3 = x4[i + 3LL * B];
+            const int c0 = c; step(); const int c1 = c; step(); const int c2 = c; step(); const int c3 = c; step();
+            put(i, v0, c0); put(i + B, v1, c1); put(i + 2LL * B, v2, c2); put(i + 3LL * B, v3, c3);
         }
+        for (; i < n4; i += B) { put(i, x4[i], c); step(); }
     } else {
         for (long long i = threadIdx.x; i < len; i += blockDim.x) {
             const int c = g * cg + (int)(i / HW);
