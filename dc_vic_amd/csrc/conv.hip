@@ -265,6 +265,7 @@ static thread_local int g_tuning_init = 0;
 static thread_local int g_use_dma = 1;   // DCVIC_CONV_DMA=0 forces the generic kernel (A/B comparisons, debugging)
 static thread_local int g_use_async = 1; // DCVIC_CONV_ASYNC=0 disables conv_async.hip
 static thread_local int g_async_fill = 2; // async twin when workgroups <= g_async_fill x CUs (DCVIC_CONV_ASYNC_FILL)
+static thread_local int g_async_fill256 = 1; // the same bound for the 256-pixel tiles (DCVIC_CONV_ASYNC_FILL256)
 static thread_local int g_use_async16 = 1; // DCVIC_CONV_ASYNC16=0: keep the 32x32x2 build of the async twin for the small tiles too
 
 static int tile_width_log(int Wout) {
@@ -396,6 +397,8 @@ static void init_num_cu() {
         if (e && e[0] == '0') g_use_async16 = 0;
         e = getenv("DCVIC_CONV_ASYNC_FILL");
         if (e && atoi(e) > 0) g_async_fill = atoi(e);
+        e = getenv("DCVIC_CONV_ASYNC_FILL256");
+        if (e && atoi(e) > 0) g_async_fill256 = atoi(e);
     }
 }
 
@@ -558,7 +561,7 @@ extern "C" int dcvic_conv2d_f32(const dcvic_conv_desc* d, const float* packed, c
         if (rc <= 0) { g_last_variant = 7000 + cls; return rc; }
     }
     // measured: the async twin wins with about one workgroup per CU, and up to g_async_fill per CU for the small tiles
-    if (!ups && g_use_async && blocks <= (long long)(P == 256 ? 1 : g_async_fill) * g_num_cu) {
+    if (!ups && g_use_async && blocks <= (long long)(P == 256 ? g_async_fill256 : g_async_fill) * g_num_cu) {
         // about one workgroup per CU: nothing hides the staging -> the DMA double-buffered twin (same values)
         // small tiles: the 16x16x4 build (four independent accumulator chains per wave), else the 32x32x2 one
         int rc = g_use_async16 ? dcvic_try_conv_async16(K, cls, P, st) : 1;
