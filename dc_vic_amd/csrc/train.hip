@@ -291,51 +291,117 @@ extern "C" int dcvic_ew_bwd_f32(int op, float* d, const float* g, const float* a
 // y = act(xh * gamma + beta), xh = (x - mean) * rstd over the group.  One workgroup per (n, group):
 //   dh = dy * act'(h);  dx = rstd * (dh*gamma - (S1 + xh * S2) / L),  S1 = sum dh*gamma, S2 = sum dh*gamma*xh
 //   per-image partials dgamma[n][c] = sum_p dh * xh, dbeta[n][c] = sum_p dh   (summed over n by dcvic_sum_rows_f32)
+// Three passes over the group (x | x, dy | x, dy -> dx) as 16-byte accesses with four loads in flight per thread: at batch 8 there are
+// only N x 32 = 256 workgroups, one per CU, so the bytes in flight per thread decide the bandwidth (scalar loads: 1.4 TB/s).  The
+// per-channel sums are wave-reduced into LDS as they finish and combined behind ONE barrier (two block reductions per channel before).
 __global__ __launch_bounds__(512) void groupnorm_bwd_kernel(const float* __restrict__ x, long long x_bs, const float* __restrict__ dy,
                                                             long long dy_bs, float* __restrict__ dx, long long dx_bs,
                                                             const float* __restrict__ gamma, const float* __restrict__ beta,
                                                             float* __restrict__ dgam, float* __restrict__ dbet, int C, int HW, int groups,
                                                             float eps, int act) {
     __shared__ double red[16];
+    __shared__ double cred[8][64][2];                              // [wave][channel of the group][dh | dh * xh]
     const int n = blockIdx.x / groups, g = blockIdx.x % groups;
     const int cg = C / groups;
     const long long len = (long long)cg * HW;
     const float* xp = x + (long long)n * x_bs + (long long)g * cg * HW;
     const float* gp = dy + (long long)n * dy_bs + (long long)g * cg * HW;
     float* dp = dx + (long long)n * dx_bs + (long long)g * cg * HW;
+    const bool vec = (HW % 4 == 0) && ((reinterpret_cast<uintptr_t>(xp) | reinterpret_cast<uintptr_t>(gp) | reinterpret_cast<uintptr_t>(dp)) % 16 == 0);
+    const int B = blockDim.x;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nw = B >> 6;
     double s = 0.0, q = 0.0;
-    for (long long i = threadIdx.x; i < len; i += blockDim.x) { const double v = xp[i]; s += v; q += v * v; }
+    if (vec) {
+        const float4* x4 = reinterpret_cast<const float4*>(xp);
+        const long long n4 = len / 4;
+        auto acc = [&](const float4 v) {
+            s += ((double)v.x + (double)v.y) + ((double)v.z + (double)v.w);
+            q += ((double)v.x * v.x + (double)v.y * v.y) + ((double)v.z * v.z + (double)v.w * v.w);
+        };
+        long long i = threadIdx.x;
+        for (; i + 3LL * B < n4; i += 4LL * B) {
+            const float4 v0 = x4[i], v1 = x4[i + B], v2 = x4[i + 2LL * B], v3 = x4[i + 3LL * B];
+            acc(v0); acc(v1); acc(v2); acc(v3);
+        }
+        for (; i < n4; i += B) acc(x4[i]);
+    } else {
+        for (long long i = threadIdx.x; i < len; i += B) { const double v = xp[i]; s += v; q += v * v; }
+    }
     const double S = bsum_d(s, red), Q = bsum_d(q, red);
     const double mean_d = S / (double)len;
     const float mean = (float)mean_d;
     const float var = (float)fmax(Q / (double)len - mean_d * mean_d, 0.0);
     const float rstd = 1.0f / sqrtf(var + eps);
-    auto dh_of = [&](long long i, int c, float& xh) {
-        xh = (xp[i] - mean) * rstd;
-        const float h = xh * gamma[c] + beta[c];
-        float d = gp[i];
-        if (act == DCVIC_ACT_SWISH) { const float sg = 1.f / (1.f + expf(-h)); d *= sg * (1.f + h * (1.f - sg)); }
+    const bool swish = act == DCVIC_ACT_SWISH;
+    auto dh1 = [&](float xv, float d, float ga, float be, float& xh) {
+        xh = (xv - mean) * rstd;
+        if (swish) { const float h = xh * ga + be; const float sg = 1.f / (1.f + expf(-h)); d *= sg * (1.f + h * (1.f - sg)); }
         return d;
     };
-    double s1 = 0.0, s2 = 0.0;
+    // ---- pass 2: per channel sum dh, sum dh * xh
     for (int cc = 0; cc < cg; ++cc) {
         const int c = g * cg + cc;
+        const float ga = gamma[c], be = beta[c];
         double a1 = 0.0, a2 = 0.0;
-        for (int i = threadIdx.x; i < HW; i += blockDim.x) {
-            float xh;
-            const float d = dh_of((long long)cc * HW + i, c, xh);
-            a1 += (double)d; a2 += (double)d * xh;
+        auto acc1 = [&](float xv, float dv) { float xh; const float d = dh1(xv, dv, ga, be, xh); a1 += (double)d; a2 += (double)d * xh; };
+        if (vec) {
+            const float4* x4 = reinterpret_cast<const float4*>(xp + (long long)cc * HW);
+            const float4* g4 = reinterpret_cast<const float4*>(gp + (long long)cc * HW);
+            const int hw4 = HW / 4;
+            auto acc4 = [&](const float4 xv, const float4 dv) { acc1(xv.x, dv.x); acc1(xv.y, dv.y); acc1(xv.z, dv.z); acc1(xv.w, dv.w); };
+            int i = threadIdx.x;
+            for (; i + B < hw4; i += 2 * B) {
+                const float4 xa = x4[i], xb = x4[i + B], da = g4[i], db = g4[i + B];
+                acc4(xa, da); acc4(xb, db);
+            }
+            for (; i < hw4; i += B) acc4(x4[i], g4[i]);
+        } else {
+            for (int i = threadIdx.x; i < HW; i += B) acc1(xp[(long long)cc * HW + i], gp[(long long)cc * HW + i]);
         }
-        const double A1 = bsum_d(a1, red), A2 = bsum_d(a2, red);
+        a1 = wsum_d(a1); a2 = wsum_d(a2);
+        if (lane == 0) { cred[wv][cc][0] = a1; cred[wv][cc][1] = a2; }
+    }
+    __syncthreads();
+    double s1 = 0.0, s2 = 0.0;
+    for (int cc = 0; cc < cg; ++cc) {                              // (every thread: the same fixed order, no second barrier)
+        double A1 = 0.0, A2 = 0.0;
+        for (int w = 0; w < nw; ++w) { A1 += cred[w][cc][0]; A2 += cred[w][cc][1]; }
+        const int c = g * cg + cc;
         if (threadIdx.x == 0) { dbet[(long long)n * C + c] = (float)A1; dgam[(long long)n * C + c] = (float)A2; }
         s1 += A1 * gamma[c]; s2 += A2 * gamma[c];
     }
     const float m1 = (float)(s1 / (double)len), m2 = (float)(s2 / (double)len);
-    for (long long i = threadIdx.x; i < len; i += blockDim.x) {
-        const int c = g * cg + (int)(i / HW);
+    // ---- pass 3: dx
+    auto dx1 = [&](float xv, float dv, float ga, float be) {
         float xh;
-        const float d = dh_of(i, c, xh);
-        dp[i] = rstd * (d * gamma[c] - (m1 + xh * m2));
+        const float d = dh1(xv, dv, ga, be, xh);
+        return rstd * (d * ga - (m1 + xh * m2));
+    };
+    if (vec) {
+        const float4* x4 = reinterpret_cast<const float4*>(xp);
+        const float4* g4 = reinterpret_cast<const float4*>(gp);
+        float4* d4 = reinterpret_cast<float4*>(dp);
+        const int hw4 = HW / 4;
+        const long long n4 = len / 4;
+        int cc = (int)threadIdx.x / hw4, j = (int)threadIdx.x - cc * hw4;
+        const int sc = B / hw4, sj = B - sc * hw4;
+        auto put = [&](long long i, const float4 xv, const float4 dv, int ch) {
+            const float ga = gamma[g * cg + ch], be = beta[g * cg + ch];
+            d4[i] = make_float4(dx1(xv.x, dv.x, ga, be), dx1(xv.y, dv.y, ga, be), dx1(xv.z, dv.z, ga, be), dx1(xv.w, dv.w, ga, be));
+        };
+        auto step = [&]() { cc += sc; j += sj; if (j >= hw4) { j -= hw4; ++cc; } };
+        long long i = threadIdx.x;
+        for (; i + B < n4; i += 2LL * B) {
+            const float4 xa = x4[i], xb = x4[i + B], da = g4[i], db = g4[i + B];
+            const int c0 = cc; step(); const int c1 = cc; step();
+            put(i, xa, da, c0); put(i + B, xb, db, c1);
+        }
+        for (; i < n4; i += B) { put(i, x4[i], g4[i], cc); step(); }
+    } else {
+        for (long long i = threadIdx.x; i < len; i += B) {
+            const int ch = (int)(i / HW);
+            dp[i] = dx1(xp[i], gp[i], gamma[g * cg + ch], beta[g * cg + ch]);
+        }
     }
 }
 extern "C" int dcvic_groupnorm_bwd_f32(const float* x, long long x_bs, const float* dy, long long dy_bs, float* dx, long long dx_bs,
@@ -343,6 +409,7 @@ extern "C" int dcvic_groupnorm_bwd_f32(const float* x, long long x_bs, const flo
                                        int groups, float eps, int act, void* stream) {
     DCVIC_CHECK_ARG(x && dy && dx && gamma && beta && dgamma_part && dbeta_part, "groupnorm_bwd: null pointer");
     DCVIC_CHECK_ARG(C % groups == 0 && (act == DCVIC_ACT_NONE || act == DCVIC_ACT_SWISH), "groupnorm_bwd: C=%d groups=%d act=%d", C, groups, act);
+    DCVIC_CHECK_ARG(C / groups <= 64, "groupnorm_bwd: %d channels per group (at most 64)", C / groups);
     groupnorm_bwd_kernel<<<N * groups, 512, 0, (hipStream_t)stream>>>(x, x_bs, dy, dy_bs, dx, dx_bs, gamma, beta, dgamma_part, dbeta_part, C, HW,
                                                                       groups, eps, act);
     DCVIC_CHECK_LAUNCH("groupnorm_bwd");

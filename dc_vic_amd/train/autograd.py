@@ -143,6 +143,7 @@ def _dgrad_plan(mod) -> ops.ConvPlan:
         plan = ops.ConvPlan(w.flip(2, 3).transpose(0, 1).contiguous(), None, "conv", pad=(k - 1 - p, k - 1 - p))
         # the data gradient of a Conv2d(k3, s1, p1) is again one: Winograd wherever the forward layer opted in (layers.allow_winograd)
         plan.wino = bool(getattr(mod, "wino", False)) and (k, p) == (3, 1)
+        plan.wino44 = plan.wino and bool(getattr(mod, "wino44", False))   # (F(4x4) where the forward layer may use it: decoder + fusion)
         return plan
     if (k, s, p) == (4, 2, 1):
         # adjoint = ConvTranspose2d(k4, s2, p1): output row 2m+py takes (input row, ky) in {(m-1, 3), (m, 1)} for py = 0 and
@@ -168,7 +169,14 @@ def conv(ctx: Ctx, x: Var, mod, act: int = ops.ACT_NONE) -> Var:
     if ups:
         # differentiable path: explicit nearest x2 then the plain 3x3 convolution (ldm model.py:53-57)
         xin = K.resample2(_dense(xd), down=False)
-        plan = ops.ConvPlan(mod.weight, mod.bias, "conv", pad=(1, 1))
+        cached = None if trainable else getattr(mod, "_plain_plan", None)
+        plan = cached[1] if cached is not None and cached[0] == mod._key() else None
+        if plan is None:
+            plan = ops.ConvPlan(mod.weight, mod.bias, "conv", pad=(1, 1))
+            plan.wino = bool(getattr(mod, "wino", False))
+            plan.wino44 = plan.wino and bool(getattr(mod, "wino44", False))
+            if not trainable:
+                mod._plain_plan = (mod._key(), plan)   # frozen weights (the VQGAN decoder's Upsample convs): pack once per weight version
     else:
         xin = xd
         if trainable:        # the weights move every step: never reuse a cached pack
@@ -179,6 +187,7 @@ def conv(ctx: Ctx, x: Var, mod, act: int = ops.ACT_NONE) -> Var:
             else:
                 plan = ops.ConvPlan(mod.weight, mod.bias, "conv", stride=mod.stride, pad=(mod.padding, mod.padding))
                 plan.wino = bool(getattr(mod, "wino", False))    # (the SFT fusion blocks train; their 3x3 convs stay on Winograd)
+                plan.wino44 = plan.wino and bool(getattr(mod, "wino44", False))
         else:
             plan = mod._get_plan()
     y = plan(xin, act=act)
@@ -192,11 +201,12 @@ def conv(ctx: Ctx, x: Var, mod, act: int = ops.ACT_NONE) -> Var:
         if act != ops.ACT_NONE:
             g = K.ew(0, g, y, act=act)
         if x.needs_grad:
-            dp = getattr(mod, "_dgrad", None)
-            if trainable or dp is None:
+            cached = getattr(mod, "_dgrad", None)
+            dp = cached[1] if (not trainable and cached is not None and cached[0] == mod._key()) else None
+            if dp is None:
                 dp = _dgrad_plan(mod)
                 if not trainable:
-                    mod._dgrad = dp
+                    mod._dgrad = (mod._key(), dp)          # keyed by the weights' version: a reloaded checkpoint rebuilds it
             dx = dp(g)
             if ups:
                 dx = K.resample2(dx, down=True)
