@@ -42,6 +42,8 @@ __device__ __forceinline__ double bsum_d(double v, double* red) {
 // the MFMA 32x32x2 operand reads (lane -> row, lane half -> pixel parity) are conflict-free.
 // Workgroup = (m block of 128, c block of 32, ky, pixel slab); 4 waves, wave w owns rows 32 w .. 32 w + 31 and KW accumulators.
 // Partials [slab][m][c][ky][kx] are reduced by wgrad_reduce_kernel in ascending slab order.
+__device__ __attribute__((aligned(16))) float dcvic_train_zero[4];   // zero-initialised: source of out-of-range elements
+
 struct WgradArgs {
     const float* G; long long g_bs; int M, Hg, Wg;       // "gradient-side" map: N x M x Hg x Wg (pixel index of the sum)
     const float* X; long long x_bs; int Cx, Hx, Wx;      // "input-side" map:    N x Cx x Hx x Wx
@@ -51,8 +53,11 @@ struct WgradArgs {
     int mblocks, cblocks;
 };
 
-template <int KWT>
-__global__ __launch_bounds__(256, 1) void conv_wgrad_kernel(const WgradArgs a) {
+// KHT = 1: the kernel row ky is a grid dimension (any KH <= 5, stride <= 4).  KHT = KH (3x3 / stride 1, the bulk of the trained
+// layers): one workgroup accumulates all KH x KW taps -- the G chunk is loaded once for nine taps instead of once per kernel row, and a
+// chunk carries 144 MFMAs per wave between two barriers instead of 48 (the first build spent 25 k cycles per chunk on 9 k of MFMAs).
+template <int KWT, int KHT>
+__global__ __launch_bounds__(256, KHT > 1 ? 2 : 1) void conv_wgrad_kernel(const WgradArgs a) {   // (KHT > 1: 144 accumulator + <= 112 other registers, two workgroups per CU)
     constexpr int PX = 32;                 // pixels per chunk (16 MFMA k-steps)
     constexpr int AS = 33;                 // A image row stride
     extern __shared__ float sm[];
@@ -61,18 +66,19 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_kernel(const WgradArgs a) {
     int b = blockIdx.x;
     const int mb = b % a.mblocks; b /= a.mblocks;
     const int cb = b % a.cblocks; b /= a.cblocks;
-    const int ky = b % a.KH; b /= a.KH;
+    int ky = 0;
+    if (KHT == 1) { ky = b % a.KH; b /= a.KH; }             // first kernel row of this workgroup
     const int slab = b;
     const int n = slab / a.slabs_per_img, srow0 = (slab % a.slabs_per_img) * a.rows_per_slab;
     const int xw = (PX - 1) * a.stride + a.KW;             // input pixels per chunk row
     const int XS = xw | 1;                                  // odd
     // double-buffered LDS images; the next chunk's global loads are in flight (registers) while this chunk's MFMAs run
-    const int XSZ = 32 * XS;
+    const int XSZ = KHT * 32 * XS;
     float* As0 = sm;                                       // 2 x [128][AS]
-    float* Xs0 = sm + 2 * 128 * AS;                        // 2 x [32][XS]
-    f32x16 acc[KWT];
+    float* Xs0 = sm + 2 * 128 * AS;                        // 2 x [KHT][32][XS]
+    f32x16 acc[KHT * KWT];
 #pragma unroll
-    for (int t = 0; t < KWT; ++t)
+    for (int t = 0; t < KHT * KWT; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
     const float* Gn = a.G + (long long)n * a.g_bs;
@@ -81,40 +87,74 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_kernel(const WgradArgs a) {
     const int rend = min(srow0 + a.rows_per_slab, a.Hg);
     const int cpr = (a.Wg + PX - 1) / PX;                  // chunks per row
     const int nchunks = max(rend - srow0, 0) * cpr;
-    constexpr int NA = 128 * PX / 256;                     // 16 A elements per thread
-    constexpr int NXMAX = (32 * (31 * 4 + 5) + 255) / 256; // covers stride <= 4, KW <= 5
-    const int nx = (32 * xw + 255) / 256;
+    constexpr int NA = 128 * PX / 256;                     // 16 A elements per thread = four 16-byte groups
+    constexpr int NA4 = NA / 4;
+    constexpr int NXMAX = KHT > 1 ? (KHT * 32 * (31 + 5) + 255) / 256 : (32 * (31 * 4 + 5) + 255) / 256;   // KHT > 1: stride 1 only; else stride <= 4, KW <= 5
+    const int nx = (KHT * 32 * xw + 255) / 256;
+    // Everything about an element that does not depend on the chunk is derived ONCE (row / column of the A group, channel and
+    // column of the X element, LDS offsets): per chunk a load costs one add and one select.  (The first build re-derived
+    // (e / xw, e % xw, 64-bit row offsets) per element and chunk: ~1 300 address instructions per 48 MFMAs -- the vector ALU, which
+    // an fp32 MFMA shares its lanes with, was busier than the matrix pipe.)  Out-of-range elements read a zero word (select on the
+    // ADDRESS: the loads stay independent of each other).
+    const bool a_vec = (a.Wg % 4 == 0) && (a.g_bs % 4 == 0) && (reinterpret_cast<uintptr_t>(a.G) % 16 == 0);
+    const int a_p4 = 4 * (tid & 7);                        // group u: row (tid >> 3) + 32 u, pixels a_p4 .. a_p4 + 3 of the chunk
+    const float* const a_base = Gn + (long long)(m0 + (tid >> 3)) * a.Hg * a.Wg + a_p4;
+    const long long a_step = 32ll * a.Hg * a.Wg;
+    int x_off[NXMAX], x_pk[NXMAX];                          // x_pk = LDS offset << 8 | kernel row << 6 | column
+#pragma unroll
+    for (int u = 0; u < NXMAX; ++u) {
+        const int e = tid + u * 256;
+        x_off[u] = -1; x_pk[u] = 0;
+        if (u < nx && e < KHT * 32 * xw) {
+            const int kyi = e / (32 * xw), e2 = e - kyi * (32 * xw);
+            const int c = e2 / xw, q = e2 - c * xw;
+            x_pk[u] = (((kyi * 32 + c) * XS + q) << 8) | (kyi << 6) | q;     // (q <= 35 for KHT > 1; KHT = 1: kyi = 0 and q < 256)
+            if (c0 + c < a.Cx) x_off[u] = (c0 + c) * a.Hx * a.Wx + q;
+        }
+    }
     float ra[NA], rx[NXMAX];
     auto fetch = [&](int ch) {
         const int oy = srow0 + ch / cpr, ox0 = (ch % cpr) * PX;
-        const int iy = oy * a.stride + ky - a.pt;
-        const bool rowok = iy >= 0 && iy < a.Hx;
+        const int iy0 = oy * a.stride + ky - a.pt;         // input row of kernel row ky (+ x_ky[u] for the others)
+        const int g_add = oy * a.Wg + ox0;
+        if (a_vec) {
 #pragma unroll
-        for (int u = 0; u < NA; ++u) {
-            const int e = tid + u * 256, r = e >> 5, p = e & 31;
-            ra[u] = (m0 + r < a.M && ox0 + p < a.Wg) ? Gn[((long long)(m0 + r) * a.Hg + oy) * a.Wg + ox0 + p] : 0.f;
+            for (int u = 0; u < NA4; ++u) {
+                const bool ok = m0 + (tid >> 3) + 32 * u < a.M && ox0 + a_p4 < a.Wg;   // (Wg % 4 == 0: a group is inside or outside the row)
+                const float4 v = *reinterpret_cast<const float4*>(ok ? a_base + u * a_step + g_add : dcvic_train_zero);
+                ra[4 * u] = v.x; ra[4 * u + 1] = v.y; ra[4 * u + 2] = v.z; ra[4 * u + 3] = v.w;
+            }
+        } else {
+#pragma unroll
+            for (int u = 0; u < NA4; ++u)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const bool ok = m0 + (tid >> 3) + 32 * u < a.M && ox0 + a_p4 + j < a.Wg;
+                    ra[4 * u + j] = *(ok ? a_base + u * a_step + g_add + j : dcvic_train_zero);
+                }
         }
         const int ix0 = ox0 * a.stride - a.pl;
 #pragma unroll
         for (int u = 0; u < NXMAX; ++u) {
-            const int e = tid + u * 256;
-            float v = 0.f;
-            if (u < nx && e < 32 * xw) {
-                const int c = e / xw, q = e - c * xw, ix = ix0 + q;
-                if (rowok && c0 + c < a.Cx && ix >= 0 && ix < a.Wx) v = Xn[((long long)(c0 + c) * a.Hx + iy) * a.Wx + ix];
+            if (u < nx) {
+                const int ix = ix0 + (KHT > 1 ? (x_pk[u] & 63) : (x_pk[u] & 255)), iy = iy0 + (KHT > 1 ? ((x_pk[u] >> 6) & 3) : 0);
+                const bool ok = x_off[u] >= 0 && iy >= 0 && iy < a.Hx && ix >= 0 && ix < a.Wx;
+                rx[u] = *(ok ? Xn + (x_off[u] + iy * a.Wx + ix0) : dcvic_train_zero);
             }
-            rx[u] = v;
         }
     };
     auto stage = [&](int buf) {
         float* As = As0 + buf * 128 * AS;
         float* Xs = Xs0 + buf * XSZ;
 #pragma unroll
-        for (int u = 0; u < NA; ++u) { const int e = tid + u * 256; As[(e >> 5) * AS + (e & 31)] = ra[u]; }
+        for (int u = 0; u < NA4; ++u) {
+            float* d = As + ((tid >> 3) + 32 * u) * AS + a_p4;
+            d[0] = ra[4 * u]; d[1] = ra[4 * u + 1]; d[2] = ra[4 * u + 2]; d[3] = ra[4 * u + 3];
+        }
 #pragma unroll
         for (int u = 0; u < NXMAX; ++u) {
             const int e = tid + u * 256;
-            if (u < nx && e < 32 * xw) { const int c = e / xw; Xs[c * XS + (e - c * xw)] = rx[u]; }
+            if (u < nx && e < KHT * 32 * xw) Xs[x_pk[u] >> 8] = rx[u];
         }
     };
     if (nchunks > 0) { fetch(0); stage(0); }
@@ -124,14 +164,18 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_kernel(const WgradArgs a) {
         if (ch + 1 < nchunks) fetch(ch + 1);
         const float* ap = As0 + buf * 128 * AS + (wave * 32 + lr) * AS + lh;
         const float* xp = Xs0 + buf * XSZ + lr * XS + lh * a.stride;
-#pragma unroll 4
+        // (fully unrolled: with a real inner loop hipcc drains the next chunk's global loads -- `s_waitcnt vmcnt(0)` -- in the loop's
+        // preheader, i.e. BEFORE the MFMAs they are meant to hide behind)
+#pragma unroll
         for (int s = 0; s < PX / 2; ++s) {
             const float av = ap[2 * s];
 #pragma unroll
-            for (int t = 0; t < KWT; ++t) {
-                const float bv = xp[2 * s * a.stride + t];
-                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[t], 0, 0, 0);
-            }
+            for (int kyi = 0; kyi < KHT; ++kyi)
+#pragma unroll
+                for (int t = 0; t < KWT; ++t) {
+                    const float bv = xp[kyi * 32 * XS + 2 * s * a.stride + t];
+                    acc[kyi * KWT + t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[kyi * KWT + t], 0, 0, 0);
+                }
         }
         if (ch + 1 < nchunks) stage(buf ^ 1);              // everyone finished reading buf ^ 1 before the previous barrier
         __syncthreads();
@@ -141,12 +185,14 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_kernel(const WgradArgs a) {
     const int c = c0 + lr;
     if (c < a.Cx) {
 #pragma unroll
-        for (int t = 0; t < KWT; ++t)
+        for (int kyi = 0; kyi < KHT; ++kyi)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = m0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                if (m < a.M && t < a.KW) P[(((long long)m * a.Cx + c) * a.KH + ky) * a.KW + t] = acc[t][r];
-            }
+            for (int t = 0; t < KWT; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int m = m0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                    if (m < a.M && t < a.KW) P[(((long long)m * a.Cx + c) * a.KH + ky + kyi) * a.KW + t] = acc[kyi * KWT + t][r];
+                }
     }
 }
 
@@ -164,7 +210,7 @@ extern "C" long long dcvic_conv_wgrad_workspace_floats(int N, int M, int Cx, int
     const int mblocks = dcvic_cdiv(M, 128), cblocks = dcvic_cdiv(Cx, 32);
     const long long base = (long long)mblocks * cblocks * KH * N;
     int per_img = 1;
-    while (base * per_img < 512 && per_img < Hg) per_img *= 2;
+    while (base * per_img < 512 && per_img < Hg) per_img *= 2;   // (measured: 1 536 is slower on every trained shape -- shorter workgroups)
     per_img = per_img > Hg ? Hg : per_img;
     const int rows = dcvic_cdiv(Hg, per_img);
     per_img = dcvic_cdiv(Hg, rows);
@@ -185,17 +231,27 @@ extern "C" int dcvic_conv_wgrad_f32(const float* G, long long g_bs, int M, int H
     a.part = workspace; a.N = N; a.KH = KH; a.KW = KW; a.stride = stride; a.pt = pt; a.pl = pl;
     a.slabs_per_img = slabs / N; a.rows_per_slab = dcvic_cdiv(Hg, a.slabs_per_img);
     a.mblocks = dcvic_cdiv(M, 128); a.cblocks = dcvic_cdiv(Cx, 32);
-    const long long blocks = (long long)a.mblocks * a.cblocks * KH * slabs;
+    // KHT = KH (all kernel rows of a 3x3 / stride-1 layer in one workgroup: G loaded once for nine taps, 144 MFMAs per barrier) is
+    // built but measured SLOWER on every trained shape (0.58 / 1.79 / 3.42 ms against 0.53 / 1.77 / 3.13: 144 accumulator registers
+    // leave one workgroup per CU or spills) -- opt-in for experiments only
+    static const bool fuse_env = getenv("DCVIC_WGRAD_FUSED") && getenv("DCVIC_WGRAD_FUSED")[0] == '1';
+    const bool rows_fused = KH == 3 && KW == 3 && stride == 1 && fuse_env;
+    const long long blocks = (long long)a.mblocks * a.cblocks * (rows_fused ? 1 : KH) * slabs;
     DCVIC_CHECK_ARG(blocks < (1ll << 31), "conv_wgrad: grid too large");
     const int xw = 31 * stride + KW;
-    const size_t lds = (size_t)2 * (128 * 33 + 32 * (xw | 1)) * sizeof(float);
+    const size_t lds = (size_t)2 * (128 * 33 + (rows_fused ? 3 : 1) * 32 * (xw | 1)) * sizeof(float);
     hipStream_t st = (hipStream_t)stream;
-    switch (KW) {
-        case 1: conv_wgrad_kernel<1><<<(unsigned)blocks, 256, lds, st>>>(a); break;
-        case 2: conv_wgrad_kernel<2><<<(unsigned)blocks, 256, lds, st>>>(a); break;
-        case 3: conv_wgrad_kernel<3><<<(unsigned)blocks, 256, lds, st>>>(a); break;
-        case 4: conv_wgrad_kernel<4><<<(unsigned)blocks, 256, lds, st>>>(a); break;
-        default: conv_wgrad_kernel<5><<<(unsigned)blocks, 256, lds, st>>>(a); break;
+    if (rows_fused) {
+        static std::atomic<unsigned> attr_mask{0};
+        if (DcvicAttrOnce once_{attr_mask})
+            hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_kernel<3, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+        conv_wgrad_kernel<3, 3><<<(unsigned)blocks, 256, lds, st>>>(a);
+    } else switch (KW) {
+        case 1: conv_wgrad_kernel<1, 1><<<(unsigned)blocks, 256, lds, st>>>(a); break;
+        case 2: conv_wgrad_kernel<2, 1><<<(unsigned)blocks, 256, lds, st>>>(a); break;
+        case 3: conv_wgrad_kernel<3, 1><<<(unsigned)blocks, 256, lds, st>>>(a); break;
+        case 4: conv_wgrad_kernel<4, 1><<<(unsigned)blocks, 256, lds, st>>>(a); break;
+        default: conv_wgrad_kernel<5, 1><<<(unsigned)blocks, 256, lds, st>>>(a); break;
     }
     DCVIC_CHECK_LAUNCH("conv_wgrad");
     const long long len = (long long)M * Cx * KH * KW;
