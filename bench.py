@@ -32,6 +32,7 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 PEAK_F32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: dense fp32 matrix peak (v_mfma_f32_32x32x2_f32)
+PEAK_HBM_TBPS = 8.0              # MI355X_MICROARCH.md: HBM3E peak (achievable ~5 - 6 TB/s)
 GFLOP_PER_IMAGE = 1009.6         # one 256x256 image, compress + decompress
 
 
@@ -279,8 +280,15 @@ def main():
                                "share_of_step_time": k["time_s"] / dt_ev,
                                "measured_over": f"{max(1, a.event_steps)} eager step(s) with per-launch HIP events right behind the timed region "
                                                 "(the timed steps replay hipGraphs, which cannot carry per-launch events); same kernels, same arguments",
+                               # per kernel: executed MFMA rate, and the rate of its ALGORITHMIC bytes (input read once, output written
+                               # once, weights; residual reads not counted) against HBM -- `bound` names the roof it sits closer to
+                               # (the 96 / 192-channel 1x1 layers and the 3-channel layers are HBM-bound: < 20 flop per byte)
                                "all_conv_kernels": {n: {"tflops": d["exec_flops"] / d["time_s"] / 1e12,
                                                         "algorithmic_tflops": d["flops"] / d["time_s"] / 1e12, "launches": d["launches"],
+                                                        "mfma_frac": d["exec_flops"] / d["time_s"] / 1e12 / PEAK_F32_MFMA_TFLOPS,
+                                                        "algorithmic_hbm_tbps": d["bytes"] / d["time_s"] / 1e12,
+                                                        "hbm_frac": d["bytes"] / d["time_s"] / 1e12 / PEAK_HBM_TBPS,
+                                                        "bound": "hbm" if d["bytes"] / PEAK_HBM_TBPS > d["exec_flops"] / PEAK_F32_MFMA_TFLOPS else "mfma",
                                                         "time_share": d["time_s"] / dt_ev} for n, d in ev.items()}}
         else:
             out["roofline"] = None

@@ -100,17 +100,21 @@ def kernel_events_start() -> None:
 
 
 def kernel_events_stop():
-    """-> {kernel name: {kernel, launches, flops (algorithmic 2*MAC), exec_flops (MFMA flops issued), time_s}}; call after a device sync."""
+    """-> {kernel name: {kernel, launches, flops (algorithmic 2*MAC), exec_flops (MFMA flops issued), bytes (algorithmic HBM bytes:
+    one read of the input, one write of the output, the weights; residual reads not counted), time_s}}; call after a device sync."""
     global _EVENTS
     ev, _EVENTS = _EVENTS, None
     out = {}
     shapes = {}
     for cfg, flops, e0, e1, shp in ev or []:
         name = conv_kernel_name(cfg)
-        d = out.setdefault(name, {"kernel": name, "launches": 0, "flops": 0.0, "exec_flops": 0.0, "time_s": 0.0})
+        d = out.setdefault(name, {"kernel": name, "launches": 0, "flops": 0.0, "exec_flops": 0.0, "bytes": 0.0, "time_s": 0.0})
         t = e0.elapsed_time(e1) * 1e-3
         d["launches"] += 1
         d["flops"] += flops
+        Cin, Cout, T, st, ups, H, W, N = shp
+        Ho, Wo = (2 * H, 2 * W) if ups else (-(-H // st), -(-W // st))
+        d["bytes"] += 4.0 * (N * Cin * H * W + N * Cout * Ho * Wo + Cout * Cin * T)
         d["exec_flops"] += flops * EXECUTED_FRACTION.get(cfg, 1.0)
         d["time_s"] += t
         sd = shapes.setdefault((cfg,) + shp, [0, 0.0, 0.0])
