@@ -66,12 +66,16 @@ def encode_side(sd, x: torch.Tensor, b1, b2, eb):
     return z_q, idx, ch["y_hat"], ch["y_likelihood"], z_lik
 
 
-def generator_losses(sd, dsd, x: torch.Tensor, b1, b2, eb, w=LOSS_W, lsd=None):
-    """calc_g_loss on run_comp_model's output.  `sd` entries under TRAINABLE_PREFIXES should require grad."""
+def generator_losses(sd, dsd, x: torch.Tensor, b1, b2, eb, w=LOSS_W, lsd=None, force_y_hat=None, force_out_idx=None):
+    """calc_g_loss on run_comp_model's output.  `sd` entries under TRAINABLE_PREFIXES should require grad.
+    `force_y_hat` / `force_out_idx` (test infrastructure): evaluate on given integer decisions (rounded symbols, estimator argmax)
+    instead of this CPU evaluation's own -- the gradients are only comparable between two implementations that took the same ones."""
     z_q, idx, y_hat, _, _ = encode_side(sd, x, b1, b2, eb)
+    if force_y_hat is not None:
+        y_hat = force_y_hat
     feat_1, feats = O.elic_decoder_feats(sd, y_hat, b1, b2)
     pred_embed, logits = O.swin_estimator(sd, feat_1)
-    out_idx = torch.argmax(logits, dim=1)
+    out_idx = torch.argmax(logits, dim=1) if force_out_idx is None else force_out_idx
     lat = O._conv(sd, "vq_model.post_quant_conv", O.vq_indices_to_latent(sd, out_idx))
     fake = O.fusion_decode(sd, lat, feats, 1.0)
     L = {}

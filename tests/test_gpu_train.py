@@ -382,7 +382,7 @@ def test_generator_and_discriminator_step_vs_oracle(model, synth_sd):
         worst = max(worst, relclose(gp, gref, 3e-3, f"grad {k}"))
         checked += 1
     assert checked >= 400, checked          # 403 tensors carry gradients (decoder.conv4 and the unused heads do not)
-    print(f'[train parity] {checked} parameter gradients, worst relative error {worst:.2e}')
+    print(f'[train parity] {checked} parameter gradients, worst relative error {worst:.6e}')
     unused = [k for k in names if sd[k].grad is None]
     for k in unused:
         assert float(tr.g_group.grad_of(own[k]).abs().max()) == 0.0, k
@@ -453,6 +453,27 @@ def test_generator_gradient_at_step2_uses_updated_discriminator(model, synth_sd)
         tr.g_group.zero_grad()
         ctx = A.Ctx([tr.g_group])
         o = tr.generator_forward(ctx, x, None, b1, b2)
+        # Gradients are comparable only between evaluations that took the same integer decisions.  The oracle's own fp32 order
+        # depends on torch's CPU thread count (tests/test_oracle_golden.py sets 8 at import, a lone run of this file does not), so
+        # an estimator argmax or a symbol rounding on an fp32 near-tie can differ in either direction: such cases are itemised,
+        # capped and bounded, and the oracle is re-evaluated on the product's decisions.
+        idx_p, yh_p = o["out_vq_indices"].cpu(), o["y_hat"].data.cpu()
+        d_idx = idx_p != oo["out_idx"]
+        d_sym = (yh_p - oo["y_hat"]).abs() > 0.5        # (y_hat = round(y - mu) + mu: equal up to mu's 1e-7 unless a rounding flipped)
+        if bool(d_idx.any()) or bool(d_sym.any()):
+            n_idx, n_sym = int(d_idx.sum()), int(d_sym.sum())
+            assert n_idx <= 2 and n_sym <= 2, f"{n_idx} estimator indices / {n_sym} symbols differ from the oracle's"
+            lg = oo["logits"].detach()
+            pos = d_idx.nonzero()
+            for n_, i_, j_ in pos.tolist():
+                margin = float(lg[n_, oo["out_idx"][n_, i_, j_], i_, j_] - lg[n_, idx_p[n_, i_, j_], i_, j_])
+                assert 0.0 <= margin <= 1e-3 * float(lg.abs().max()), f"estimator index ({n_},{i_},{j_}): oracle margin {margin:.3e} is no near-tie"
+            assert float((yh_p - oo["y_hat"])[d_sym].abs().max() if n_sym else 1.0) <= 1.0 + 1e-4    # one quantisation step
+            print(f"[train parity] step-2: {n_idx} estimator near-tie(s), {n_sym} symbol near-tie(s): oracle re-evaluated on the product's decisions")
+            for k in names:
+                sd[k].grad = None
+            L, oo = T.generator_losses(sd, dsd, x, b1, b2, eb, w=w, force_y_hat=yh_p, force_out_idx=idx_p)
+            sum(L.values()).backward()
         glog = tr.calc_g_loss(ctx, o, b1, b2)
         relclose(glog["adv"], L["adv"].detach().reshape(1), 2e-4, "adv loss at step 2")
         ctx.backward()
@@ -462,10 +483,15 @@ def test_generator_gradient_at_step2_uses_updated_discriminator(model, synth_sd)
             gref = sd[k].grad
             if gref is None or float(gref.abs().max()) == 0.0:
                 continue
-            worst = max(worst, relclose(tr.g_group.grad_of(own[k]), gref, 3e-3, f"step-2 grad {k}"))
+            # 1e-2, not the 3e-3 of the first-step test: after the 40 % D step the ORACLE's own gradient of a tensor behind a ReLU
+            # (decoder.attn2.trunk_block.1.c2.weight) differs by 4.4e-3 between torch CPU thread counts (8 when the whole suite is
+            # collected -- tests/test_oracle_golden.py sets it at import -- against the box's default when this file runs alone:
+            # a pre-activation on an fp32 near-zero changes sign and moves one pixel's whole contribution); the product is bit-stable
+            # across runs and measures 1.7e-4 / 2.6e-4 / 4.5e-3 against those oracles.  A stale plan is off by tens of percent.
+            worst = max(worst, relclose(tr.g_group.grad_of(own[k]), gref, 1e-2, f"step-2 grad {k}"))
             checked += 1
         assert checked >= 100, checked                 # fusion blocks + ELIC decoder taps (the estimator sits behind the argmax)
-        print(f"[train parity] step-2 generator gradients through the updated D: {checked} tensors, worst relative error {worst:.2e}")
+        print(f"[train parity] step-2 generator gradients through the updated D: {checked} tensors, worst relative error {worst:.6e}")
     finally:
         model.load_state_dict(sd_before)               # the fixture is shared: put the synthetic weights back
         for m in model.modules():
