@@ -10,13 +10,20 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 #define GK 16
 
+__device__ float dcvic_gemm_zero[4];    // zero-initialised: source of out-of-range elements
+
+// Staging: element (k, m) of a stage is chunk-invariant per thread, so its global offset, LDS slot and row validity are derived once;
+// the next stage's 16 loads are issued BEFORE this stage's MFMAs and stored to the other LDS buffer after them (one barrier per stage).
+// Out-of-range elements read a zero word: a select on the loaded VALUE makes hipcc guard every load with its own exec-masked block and
+// `s_waitcnt vmcnt(0)` (sixteen serial round trips per stage -- the first build ran at 0.18 of the matrix pipe).
 template <int GT>
 __global__ __launch_bounds__(256, 2) void bgemm_kernel(const dcvic_gemm_args g) {
     constexpr int GTP = GT + 1;
     constexpr int WT = GT / 2;            // per-wave tile edge
     constexpr int MI = WT / 32;           // 32x32 accumulators per wave and dimension
-    __shared__ float As[GK * GTP];
-    __shared__ float Bs[GK * GTP];
+    constexpr int NE = GK * GT / 256;     // elements per thread, operand and stage
+    __shared__ float As[2][GK * GTP];
+    __shared__ float Bs[2][GK * GTP];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int lane_k = lane >> 5, lane_j = lane & 31;
@@ -38,34 +45,52 @@ __global__ __launch_bounds__(256, 2) void bgemm_kernel(const dcvic_gemm_args g) 
 
     const bool a_kfast = (g.a_ks == 1);   // k contiguous in memory -> walk k fastest for coalescing
     const bool b_kfast = (g.b_ks == 1);
-    for (int k0 = 0; k0 < g.K; k0 += GK) {
-        for (int e = tid; e < GK * GT; e += 256) {
-            int kk, mm;
-            if (a_kfast) { kk = e % GK; mm = e / GK; } else { mm = e % GT; kk = e / GT; }
-            float v = 0.f;
-            if (m0 + mm < g.M && k0 + kk < g.K) v = A[(long long)(m0 + mm) * g.a_ms + (long long)(k0 + kk) * g.a_ks];
-            As[kk * GTP + mm] = v;
+    long long a_off[NE], b_off[NE];       // -1: row / column outside the matrix
+    int a_pk[NE], b_pk[NE];               // LDS slot << 8 | k
+#pragma unroll
+    for (int u = 0; u < NE; ++u) {
+        const int e = tid + u * 256;
+        int kk, mm;
+        if (a_kfast) { kk = e % GK; mm = e / GK; } else { mm = e % GT; kk = e / GT; }
+        a_off[u] = (m0 + mm < g.M) ? (long long)(m0 + mm) * g.a_ms + (long long)kk * g.a_ks : -1;
+        a_pk[u] = ((kk * GTP + mm) << 8) | kk;
+        int kb, nn;
+        if (b_kfast) { kb = e % GK; nn = e / GK; } else { nn = e % GT; kb = e / GT; }
+        b_off[u] = (n0 + nn < g.N) ? (long long)kb * g.b_ks + (long long)(n0 + nn) * g.b_ns : -1;
+        b_pk[u] = ((kb * GTP + nn) << 8) | kb;
+    }
+    float ra[NE], rb[NE];
+    auto fetch = [&](int k0) {
+        const long long ak = (long long)k0 * g.a_ks, bk = (long long)k0 * g.b_ks;
+#pragma unroll
+        for (int u = 0; u < NE; ++u) {
+            ra[u] = *((a_off[u] >= 0 && k0 + (a_pk[u] & 255) < g.K) ? A + (a_off[u] + ak) : dcvic_gemm_zero);
+            rb[u] = *((b_off[u] >= 0 && k0 + (b_pk[u] & 255) < g.K) ? B + (b_off[u] + bk) : dcvic_gemm_zero);
         }
-        for (int e = tid; e < GK * GT; e += 256) {
-            int kk, nn;
-            if (b_kfast) { kk = e % GK; nn = e / GK; } else { nn = e % GT; kk = e / GT; }
-            float v = 0.f;
-            if (n0 + nn < g.N && k0 + kk < g.K) v = B[(long long)(k0 + kk) * g.b_ks + (long long)(n0 + nn) * g.b_ns];
-            Bs[kk * GTP + nn] = v;
-        }
-        __syncthreads();
+    };
+    auto stage = [&](int buf) {
+#pragma unroll
+        for (int u = 0; u < NE; ++u) { As[buf][a_pk[u] >> 8] = ra[u]; Bs[buf][b_pk[u] >> 8] = rb[u]; }
+    };
+    fetch(0); stage(0);
+    __syncthreads();
+    int buf = 0;
+    for (int k0 = 0; k0 < g.K; k0 += GK, buf ^= 1) {
+        const bool more = k0 + GK < g.K;
+        if (more) fetch(k0 + GK);
 #pragma unroll
         for (int ks = 0; ks < GK / 2; ++ks) {
             float a[MI], bb[MI];
 #pragma unroll
-            for (int i = 0; i < MI; ++i) a[i] = As[(2 * ks + lane_k) * GTP + wm * WT + i * 32 + lane_j];
+            for (int i = 0; i < MI; ++i) a[i] = As[buf][(2 * ks + lane_k) * GTP + wm * WT + i * 32 + lane_j];
 #pragma unroll
-            for (int j = 0; j < MI; ++j) bb[j] = Bs[(2 * ks + lane_k) * GTP + wn * WT + j * 32 + lane_j];
+            for (int j = 0; j < MI; ++j) bb[j] = Bs[buf][(2 * ks + lane_k) * GTP + wn * WT + j * 32 + lane_j];
 #pragma unroll
             for (int i = 0; i < MI; ++i)
 #pragma unroll
                 for (int j = 0; j < MI; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], bb[j], acc[i][j], 0, 0, 0);
         }
+        if (more) stage(buf ^ 1);           // everyone finished reading buf ^ 1 before the previous barrier
         __syncthreads();
     }
     float* C = g.C + (long long)b * g.c_bs;
