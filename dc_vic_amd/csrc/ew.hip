@@ -1,6 +1,7 @@
 // ew.hip -- elementwise combiners, per-channel affine (beta-FT), strided plane copies with reflect
 // padding, crop+clamp(+uint8).  All HBM-bound; planes are dense so float4 is used when aligned.
 #include "common.h"
+#include <algorithm>
 
 // y = f(a, b, c) over [N][C][HW] views with independent batch strides.
 __global__ __launch_bounds__(256) void ew_kernel(int op, float* __restrict__ y, long long y_bs, const float* __restrict__ a,
@@ -151,23 +152,27 @@ extern "C" int dcvic_copy_window_f32(float* dst, long long dst_bs, long long dst
     return DCVIC_OK;
 }
 
-// out[n] = max |x| over one image (fixed-order tree -> deterministic)
+// out[n] = max |x| over one image.  A maximum does not depend on the order it is taken in, so an image is split over several workgroups
+// whose results meet in one atomicMax on the bit pattern (|x| >= 0: IEEE order = unsigned order): deterministic.  (One workgroup per
+// image took 1.9 ms on the 2 M latents of a 1280x2048 image.)  `out` must hold zeros on entry (the launcher clears it).
 __global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ x, long long x_bs, float* __restrict__ out,
-                                                     long long CHW) {
+                                                     long long CHW, int parts) {
     __shared__ float red[4];
-    const int n = blockIdx.x;
+    const int n = blockIdx.x / parts, part = blockIdx.x % parts;
     float m = 0.f;
-    for (long long i = threadIdx.x; i < CHW; i += blockDim.x) m = fmaxf(m, fabsf(x[n * x_bs + i]));
+    for (long long i = (long long)part * blockDim.x + threadIdx.x; i < CHW; i += (long long)parts * blockDim.x) m = fmaxf(m, fabsf(x[n * x_bs + i]));
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
     __syncthreads();
-    if (threadIdx.x == 0) out[n] = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    if (threadIdx.x == 0) atomicMax(reinterpret_cast<unsigned*>(out + n), __float_as_uint(fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]))));
 }
 
 extern "C" int dcvic_absmax_f32(const float* x, long long x_bs, float* out, int N, long long CHW, void* stream) {
     DCVIC_CHECK_ARG(x && out && N > 0 && CHW > 0, "absmax: bad argument");
-    absmax_kernel<<<N, 256, 0, (hipStream_t)stream>>>(x, x_bs, out, CHW);
+    const int parts = (int)std::min<long long>(256, std::max<long long>(1, CHW / 16384));
+    if (hipMemsetAsync(out, 0, (size_t)N * sizeof(float), (hipStream_t)stream) != hipSuccess) { dcvic_set_error("absmax: memset failed"); return DCVIC_EINVAL; }
+    absmax_kernel<<<N * parts, 256, 0, (hipStream_t)stream>>>(x, x_bs, out, CHW, parts);
     DCVIC_CHECK_LAUNCH("absmax");
     return DCVIC_OK;
 }

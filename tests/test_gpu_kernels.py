@@ -1011,3 +1011,17 @@ def test_groupnorm_statistics_from_the_wino44_epilogue(dev):
     assert p2.last_gn_part is None
     with pytest.raises(ValueError):
         ops.groupnorm(y[:, :128].contiguous(), g[:128], be[:128], 32, 1e-6, ops.ACT_SWISH, part=(part, n_pt))
+
+
+@pytest.mark.parametrize("shape", [(3, 192, 16, 16), (1, 192, 80, 128), (2, 5, 3, 7)])
+def test_absmax_matches_torch(dev, shape):
+    """max |y_hat| per image (the header's third byte, codec_utils.py:16-47): split over workgroups that meet in an order-free
+    atomic max -- exact, also through a batch-strided view."""
+    from dc_vic_amd import ops
+    x = rnd(*shape, seed=77, scale=7.0)
+    x[0, 0, 0, 0] = -123.5                                   # the maximum is a negative value's magnitude
+    got = ops.absmax(x.to(dev)).cpu()
+    assert torch.equal(got, x.abs().amax(dim=(1, 2, 3)))
+    big = rnd(shape[0], shape[1] + 3, shape[2], shape[3], seed=78).to(dev)
+    view = big[:, 1:1 + shape[1]]
+    assert torch.equal(ops.absmax(view).cpu(), view.cpu().abs().amax(dim=(1, 2, 3)))
