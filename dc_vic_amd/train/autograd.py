@@ -78,6 +78,8 @@ class ParamGroup:
         """The flat buffer was updated in place (Adam kernel): cached packed weights / beta vectors are stale."""
         for mod in self.modules:
             for m in mod.modules():
+                if hasattr(m, "_graphs"):
+                    m._graphs.clear()          # (a whole model in the group: its captured hipGraphs hold the old packed weights)
                 if hasattr(m, "_plan"):
                     m._plan = None
                 if hasattr(m, "_qkv_plan"):

@@ -159,10 +159,18 @@ class DualBetaCondGanDistortionVqCodeTrainer:
             self.rng.set_state(st["rng"])
         return int(st["iter"])
 
+    def _drop_inference_graphs(self) -> None:
+        """The generator's weights moved in place: hipGraphs captured by compress_batch / decompress_batch before that replay the old
+        packed weights -- forget them (the next inference call re-captures)."""
+        g = getattr(self.model, "_graphs", None)
+        if g is not None:
+            g.clear()
+
     def resync_parameters(self) -> None:
         """After a state dict was loaded into the modules: parameters are views of the flat buffers, so load_state_dict's copy_
         already wrote them; cached packed weights are stale."""
         self.g_group.refresh_plans(); self.d_group.refresh_plans()
+        self._drop_inference_graphs()
 
     # hyperprior_dc_vic_model.py:99-110
     def sample_selected_beta_pair(self, n: int) -> Tuple[Tensor, Tensor]:
@@ -227,6 +235,7 @@ class DualBetaCondGanDistortionVqCodeTrainer:
         if self.clip:
             gscale = K.clip_scale(K.reduce_loss(2, self.g_group.grad, None, 1.0), self.clip)
         self.g_opt.step(self.g_sched.lr(), gscale)
+        self._drop_inference_graphs()
         lr_now = self.g_sched.lr()
         self.g_sched.step()
         # ---------------------------------------------------------------- train D

@@ -537,3 +537,33 @@ def test_training_steps_256_and_checkpoint(model, tmp_path):
     assert r2["string_list"] == r["string_list"]
     img2, _, _ = m2.decompress(r2["string_list"])
     assert torch.equal(img2, img)
+
+
+def test_training_step_invalidates_inference_graphs(model):
+    """compress_batch / decompress_batch replay hipGraphs that hold the packed weights they were captured with; an optimizer step moves
+    the decoder / estimator / fusion weights in place, so the trainer drops those graphs: inference right after a step equals the eager
+    path on the NEW weights (and differs from the reconstruction before the step)."""
+    from dc_vic_amd.train import DualBetaCondGanDistortionVqCodeTrainer
+    sd_before = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    try:
+        model.codec_setup()
+        x = (torch.rand((2, 3, 64, 64), generator=torch.Generator().manual_seed(97)) * 2 - 1).to(DEV)
+        model._graphs.clear()
+        for _ in range(3):                                   # eager, capture, replay
+            r = model.compress_batch(x, 0)
+            rec0 = model.decompress_batch(r["string_lists"])[0].clone()
+        assert {k[0] for k in model._graphs.entries} == {"enc", "dec"}, list(model._graphs.entries)
+        tr = DualBetaCondGanDistortionVqCodeTrainer(model, _disc(5).to(DEV), lr_g=1e-3, lr_d=1e-4, clip_max_norm=None, seed=3)
+        assert tr.optimize_parameters(0, dict(real_images=x.cpu(), beta_rate=torch.tensor([2.29, 2.29]), beta_vq=torch.tensor([3.0, 3.0]))) is not None
+        assert len(model._graphs.entries) == 0
+        rec1 = model.decompress_batch(r["string_lists"])[0].clone()
+        model._graphs.disabled = True
+        try:
+            rec_eager = model.decompress_batch(r["string_lists"])[0]
+        finally:
+            model._graphs.disabled = False
+        assert torch.equal(rec1, rec_eager)
+        assert float((rec1 - rec0).abs().max()) > 1e-4      # the step really changed the decoder side
+    finally:
+        model.load_state_dict(sd_before)
+        tr = None
