@@ -99,7 +99,9 @@ class _GraphCache:
                         fn(*static_in)
                     torch.cuda.current_stream().wait_stream(side)
                 graph = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(graph):
+                # thread_local: only THIS thread's calls are policed during the capture -- under torch.distributed the RCCL watchdog
+                # thread polls events at any time, which the default (global) mode would turn into a failed capture
+                with torch.cuda.graph(graph, capture_error_mode="thread_local"):
                     out = fn(*static_in)
             except Exception as e:                     # noqa: BLE001 -- any capture failure means "stay eager"
                 self.disabled = True
