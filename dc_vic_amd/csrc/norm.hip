@@ -147,11 +147,43 @@ __global__ __launch_bounds__(256) void layernorm_c_kernel(const float* __restric
     for (int c = 0; c < C; ++c) yp[(long long)c * HW] = (xp[(long long)c * HW] - mean) * rstd * gamma[c] + beta[c];
 }
 
+// The same arithmetic (identical order: results are the same bits) with the pixel's C <= CMAX values held in registers: one read and
+// one write of the map instead of three reads and one write, and CMAX independent loads in flight per thread (the loop form ran at
+// 0.9 TB/s on the estimator's 128-channel maps).
+template <int CMAX>
+__global__ __launch_bounds__(64) void layernorm_c_reg_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                             const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                             int C, int HW, float eps) {
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    const int n = blockIdx.y;
+    if (p >= HW) return;
+    const float* xp = x + (long long)n * C * HW + p;
+    float* yp = y + (long long)n * C * HW + p;
+    float v[CMAX];
+#pragma unroll
+    for (int c = 0; c < CMAX; ++c) v[c] = c < C ? xp[(long long)c * HW] : 0.f;
+    float s = 0.f;
+#pragma unroll
+    for (int c = 0; c < CMAX; ++c) if (c < C) s += v[c];
+    const float mean = s / (float)C;
+    float q = 0.f;
+#pragma unroll
+    for (int c = 0; c < CMAX; ++c) if (c < C) { const float a = v[c] - mean; q += a * a; }
+    const float rstd = 1.0f / sqrtf(q / (float)C + eps);
+#pragma unroll
+    for (int c = 0; c < CMAX; ++c) if (c < C) yp[(long long)c * HW] = (v[c] - mean) * rstd * gamma[c] + beta[c];
+}
+
 extern "C" int dcvic_layernorm_c_f32(const float* x, float* y, const float* gamma, const float* beta, int N, int C, int HW,
                                      float eps, void* stream) {
     DCVIC_CHECK_ARG(x && y && gamma && beta && N > 0 && C > 0 && HW > 0, "layernorm_c: bad argument");
-    dim3 grid(dcvic_cdiv(HW, 256), N);
-    layernorm_c_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(x, y, gamma, beta, C, HW, eps);
+    if (C <= 128 && N <= 65535) {
+        dim3 grid(dcvic_cdiv(HW, 64), N);
+        layernorm_c_reg_kernel<128><<<grid, 64, 0, (hipStream_t)stream>>>(x, y, gamma, beta, C, HW, eps);
+    } else {
+        dim3 grid(dcvic_cdiv(HW, 256), N);
+        layernorm_c_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(x, y, gamma, beta, C, HW, eps);
+    }
     DCVIC_CHECK_LAUNCH("layernorm_c");
     return DCVIC_OK;
 }
